@@ -1,0 +1,185 @@
+/* libuformer_hip -- C ABI of the MI355X (gfx950) Uformer LeWin-block hot path.
+ *
+ * The reference (ZhendongWang6/Uformer) has no FFI / operator API: its de-facto boundary is
+ * the nn.Module surface of model.py.  This header is what a binding for that path would bind:
+ * one entry point per reference function on the hot path, plus the
+ * whole-block and whole-model drivers.  Each declaration cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates,
+ *     frees or retains memory; `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream); all work is enqueued on it, nothing synchronises.
+ *   - return value: 0 = UF_OK, negative = error; uf_last_error() gives the text (thread local).
+ *     Nothing throws or aborts across this boundary.
+ *   - tokens are channel-last:  x[b][h][w][c]  ==  the reference's (B, L=H*W, C) layout.
+ *   - `dtype` (uf_dtype) is the type T of GEMM operands and of intermediate activations
+ *     (UF_F32: exact-f32 MFMA, the 1e-3 parity mode; UF_BF16: bf16 operands, f32 accumulate).
+ *     The residual stream, LayerNorm/softmax/GELU math, biases and all small tables are f32.
+ *   - residual-stream tensors carry a row stride `ld` (elements) so that an encoder stage can
+ *     live inside the second half of a decoder concat buffer (model.py:1288 torch.cat).
+ *   - window size is 8 (every shipped arch, utils/model_utils.py:65-78); H, W multiples of 8.
+ */
+#ifndef UFORMER_HIP_H
+#define UFORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UF_ABI_VERSION 1
+
+typedef enum { UF_F32 = 0, UF_BF16 = 1 } uf_dtype;
+
+#define UF_OK 0
+#define UF_ERR_SHAPE (-1)
+#define UF_ERR_UNSUPPORTED (-2)
+#define UF_ERR_ALIGN (-3)
+#define UF_ERR_LAUNCH (-4)
+#define UF_ERR_WORKSPACE (-5)
+#define UF_ERR_NULL (-6)
+
+int uf_version(void);
+/* copies the calling thread's last error text (NUL terminated) into buf; returns its length */
+int uf_last_error(char* buf, size_t n);
+
+/* ---- diagnostics (not part of the reference surface) --------------------------------------
+ * uf_timing_enable(1): every kernel launch is bracketed by HIP events on its own stream and its
+ * algorithmic flops/bytes are booked per kernel class.  uf_timing_report() waits for the events,
+ * writes a JSON array [{"kernel","launches","ms","flops","bytes"},...] and clears the log;
+ * returns the length the full text needs.  bench.py uses it for the live roofline figure. */
+int uf_timing_enable(int on);
+int uf_timing_report(char* json, size_t n);
+
+/* ---- a1-a4: index-only ops (bit exact) -------------------------------------------------- */
+/* torch.roll(x,(-shift,-shift)) + window_partition: model.py:957, :704-715.
+ * x (B,H,W,C) -> out (B*nW, 8, 8, C); elem_bytes in {2,4}; pure copy. */
+int uf_window_partition(const void* x, void* out, int B, int H, int W, int C, int shift,
+                        int elem_bytes, void* stream);
+/* window_reverse + torch.roll(+shift): model.py:717-726, :980. */
+int uf_window_reverse(const void* windows, void* out, int B, int H, int W, int C, int shift,
+                      int elem_bytes, void* stream);
+/* SW-MSA mask (nW,64,64) f32 in {0,-100}: model.py:924-942.  The attention kernel evaluates
+ * the same predicate in registers; this entry materialises it for the bit-exact test. */
+int uf_shift_mask(float* out, int H, int W, int shift, void* stream);
+
+/* ---- a5/a6: LayerNorm (+ roll + partition + modulator) ---------------------------------- */
+/* out[m] = LN(x[src(m)]) * gamma + beta (+ modulator[m % 64]);  eps 1e-5, biased variance.
+ * windowed != 0: src(m) = roll/partition index (norm1 path, model.py:952-969);
+ * windowed == 0: src(m) = m (norm2 path, model.py:987).  x f32 [rows][ld_x]; out T [rows][C]. */
+int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, const float* beta,
+                     const float* modulator /* (64,C) or NULL */, void* out, int B, int H, int W,
+                     int C, int windowed, int shift, uf_dtype dtype, void* stream);
+
+/* ---- a7/a9/a10: nn.Linear  out = act(A @ W^T + bias)  (model.py:426-427,489,657,661) ------
+ * A T[M][K], W T[N][K] (nn.Linear layout), bias f32[N], out T[M][N]; act 0=none 1=erf-GELU. */
+int uf_linear_fwd(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                  int act, uf_dtype dtype, void* stream);
+
+/* ---- a7: fused Q/K/V projection (LinearProjection.forward, model.py:431-442) --------------
+ * A T[M][C] window-order tokens; Wqkv T[3C][C] = cat(to_q.weight, to_kv.weight); bias f32[3C].
+ * Writes q T[M/64][heads][64][hd] (already multiplied by hd^-0.5, model.py:497),
+ *        k T[M/64][heads][64][hd],  vt T[M/64][heads][hd][64] (V transposed per window/head). */
+int uf_qkv_fwd(const void* A, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt,
+               int M, int C, int heads, uf_dtype dtype, void* stream);
+
+/* ---- a8: window attention core (WindowAttention.forward model.py:494-519, without proj) ---
+ * q,k,vt as produced by uf_qkv_fwd.  bias_dense f32[heads][64][64] =
+ * relative_position_bias_table[relative_position_index] permuted (model.py:500-502).
+ * shift>0 adds the SW-MSA mask analytically (window position from H,W);  mask (optional,
+ * f32 [n_mask][64][64], row = window index % n_mask, model.py:508-512) is added on top.
+ * out T[M][C], channel = head*hd + d (model.py:519). */
+int uf_window_attention_fwd(const void* q, const void* k, const void* vt, const float* bias_dense,
+                            const float* mask, int n_mask, void* out, int n_windows, int heads,
+                            int head_dim, int H, int W, int shift, uf_dtype dtype, void* stream);
+
+/* ---- a10: depthwise 3x3 + bias + GELU on token layout (LeFF dwconv, model.py:659-660) -----
+ * x,out T[B][H][W][C]; w9 f32[9][C] (tap-major repack of (C,1,3,3)); bias f32[C]. */
+int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B,
+                          int H, int W, int C, uf_dtype dtype, void* stream);
+
+/* ---- per-block parameters (packed; SURVEY.md Appendix C names in comments) ----------------- */
+typedef struct uf_block_params {
+    const float* norm1_w;   /* norm1.weight (C) */
+    const float* norm1_b;   /* norm1.bias */
+    const float* modulator; /* modulator.weight (64,C) or NULL */
+    const float* rpb_dense; /* (heads,64,64) gathered from attn.relative_position_bias_table */
+    const void* wqkv;       /* T (3C,C): attn.qkv.to_q.weight ; attn.qkv.to_kv.weight */
+    const float* bqkv;      /* (3C) */
+    const void* wproj;      /* T (C,C) attn.proj.weight */
+    const float* bproj;     /* (C) */
+    const float* norm2_w;
+    const float* norm2_b;
+    const void* w1;         /* T (4C,C) mlp.linear1.0.weight */
+    const float* b1;        /* (4C) */
+    const float* wdw9;      /* (9,4C) tap-major repack of mlp.dwconv.0.weight (4C,1,3,3) */
+    const float* bdw;       /* (4C) */
+    const void* w2;         /* T (C,4C) mlp.linear2.0.weight */
+    const float* b2;        /* (C) */
+    int32_t shift;          /* 0 or 4, decided at construction (model.py:1030, :863-866) */
+    int32_t heads;
+} uf_block_params;
+
+/* bytes of scratch a block needs for M = B*H*W tokens of width C */
+size_t uf_block_workspace_bytes(int M, int C, uf_dtype dtype);
+
+/* ---- a11: attention half of LeWinTransformerBlock.forward (model.py:951-986) --------------
+ * x = x + proj(attn(partition(roll(LN1(x))) + modulator)) ; in place on the f32 stream. */
+int uf_lewin_attn_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                      const float* user_mask, int n_mask, uf_dtype dtype, void* ws,
+                      size_t ws_bytes, void* stream);
+/* ---- a10/a11: FFN half (model.py:987): x = x + LeFF(LN2(x)) ; in place. */
+int uf_leff_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* whole block = the two halves */
+int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                       const float* user_mask, int n_mask, uf_dtype dtype, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* ---- a12: Downsample.forward (Conv2d k4 s2 p1 on tokens, model.py:739-746) -----------------
+ * x f32[B][H][W] rows of C (stride ld_x); w T[2C][16C] with k = (ky*4+kx)*C + c; out f32
+ * [B][H/2][W/2] rows of 2C (stride ld_o). */
+int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out,
+                      int ld_o, int B, int H, int W, int C, uf_dtype dtype, void* stream);
+/* ---- a13: Upsample.forward (ConvTranspose2d k2 s2, model.py:765-771) written straight into
+ * the concat buffer: out rows (stride ld_o) at [B][2H][2W], channels [0,Cout).
+ * w T[4*Cout][Cin], n = (dy*2+dx)*Cout + co. */
+int uf_upsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out,
+                    int ld_o, int B, int H, int W, int Cin, int Cout, uf_dtype dtype, void* stream);
+/* ---- a14: InputProj (conv3x3 + LeakyReLU(0.01), model.py:795-800): img f32 NCHW (B,Cin,H,W)
+ * -> tokens f32 rows of E (stride ld_o); w27 f32[Cin*9][E] ((ci,ky,kx)-major repack). */
+int uf_input_proj_fwd(const float* img, const float* w27, const float* bias, float* out, int ld_o,
+                      int B, int Cin, int H, int W, int E, void* stream);
+/* ---- a14: OutputProj + global residual (model.py:828-836, :1305): tokens f32 rows of C2
+ * (stride ld_x) -> out f32 NCHW (B,3,H,W) = conv3x3(tokens) + bias (+ img if add_img).
+ * w f32[3][9][C2] ((co,ky,kx)-major repack of (3,C2,3,3)). */
+int uf_output_proj_fwd(const float* x, int ld_x, const float* w, const float* bias,
+                       const float* img, float* out, int B, int H, int W, int C2, int add_img,
+                       void* stream);
+
+/* ---- a9 (boundary): Uformer.forward (model.py:1269-1305) ------------------------------------ */
+typedef struct uf_model_desc {
+    int32_t embed_dim, dd_in, in_chans;
+    int32_t depths[9];
+    const uf_block_params* blocks; /* sum(depths) entries, stage-major (enc0..3, conv, dec0..3) */
+    const float* in_w27;   /* input_proj.proj.0.weight repacked */
+    const float* in_b;
+    const float* out_w;    /* output_proj.proj.0.weight repacked */
+    const float* out_b;
+    const void* down_w[4]; /* dowsample_i.conv.0.weight repacked T[2C][16C] */
+    const float* down_b[4];
+    const void* up_w[4];   /* upsample_i.deconv.0.weight repacked T[4Cout][Cin] */
+    const float* up_b[4];
+} uf_model_desc;
+
+size_t uf_uformer_workspace_bytes(const uf_model_desc* d, int B, int H, int W, uf_dtype dtype);
+/* img, out: f32 NCHW (B,dd_in,H,W) / (B,in_chans,H,W).  H == W, multiple of 128. */
+int uf_uformer_fwd(const uf_model_desc* d, const float* img, float* out, int B, int H, int W,
+                   uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UFORMER_HIP_H */

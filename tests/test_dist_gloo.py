@@ -1,0 +1,60 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing of bench.py / uformer_amd.dist.
+Inference shards the batch with NO data-path collective; ranks only meet for the wall-clock
+(max over ranks) and for an optional output gather.  The per-rank compute is stood in for by the
+oracle (tests may use it), so the sharded result must equal the single-process result."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import uformer_oracle as O
+    from uformer_amd import dist as ud
+    from uformer_amd import spec
+    torch.set_num_threads(2)
+    r, lr, w = ud.init_process_group("gloo")
+    assert (r, w) == (rank, world)
+    cfg = spec.arch_config("tiny", 128)
+    sd = spec.synth_state_dict(cfg, 5)
+    gb = 3                                             # uneven: rank 0 gets 2 images, rank 1 gets 1
+    x = spec.synth_input(gb, 128, 128, 6)
+    a, b = ud.shard_batch(gb, rank, world)
+    y = O.uformer_forward(x[a:b], sd, img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
+    ud.barrier()
+    t = ud.max_over_ranks(1.0 + rank)                  # slowest rank defines the step time
+    n = ud.sum_over_ranks(float(b - a))
+    full = ud.gather_batch(y, gb)
+    if rank == 0:
+        ref = O.uformer_forward(x, sd, img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
+        q.put((t, n, float((full - ref).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_inference_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    t, n, err = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 2.0 and n == 3.0
+    assert err < 1e-5

@@ -1,0 +1,91 @@
+"""CPU: host-side logic of the boundary -- state_dict layout, constructor semantics, weight
+re-layouts (checked against the oracle's arithmetic on CPU tensors), sharding helpers."""
+import numpy as np
+import torch
+
+from oracle import uformer_oracle as O
+from uformer_amd import dist as ud
+from uformer_amd import model, packing, spec
+
+
+def test_state_dict_layout_all_archs():
+    for arch, n in (("Uformer_T", None), ("Uformer_S", None), ("Uformer_B", 759)):
+        m = model.get_arch(arch, 128)
+        cfg = m.cfg
+        sp = spec.state_dict_spec(cfg)
+        sd = m.state_dict()
+        assert list(sd.keys()) == [k for k, _, _ in sp]
+        for k, shape, kind in sp:
+            assert tuple(sd[k].shape) == tuple(shape), k
+            assert sd[k].dtype == (torch.int64 if kind == "rpi" else torch.float32), k
+        if n:
+            assert len(sd) == n
+    assert sum(p.numel() for p in model.get_arch("Uformer_B", 128).parameters()) == 50880946
+
+
+def test_ctor_clamp_and_modulator_placement():
+    m = model.get_arch("Uformer_B", 128)
+    assert [b.shift_size for b in m.conv.blocks] == [0, 0]            # model.py:863-866 at 8x8
+    m = model.get_arch("Uformer_B", 256)
+    assert [b.shift_size for b in m.conv.blocks] == [0, 4]
+    assert [b.shift_size for b in m.encoderlayer_2.blocks] == [0, 4] * 4
+    assert m.encoderlayer_0.blocks[0].modulator is None                # encoder: no modulator
+    assert m.decoderlayer_3.blocks[0].modulator.weight.shape == (64, 64)
+    assert m.cfg.block_shifts() == [[b.shift_size for b in getattr(m, s).blocks] for s in spec.STAGES]
+    assert abs(m.flops() / 1e9 - 86.574) < 1e-2                        # exact MACs, SURVEY section 8d
+
+
+def test_load_checkpoint_forms():
+    cfg = spec.arch_config("tiny", 128)
+    sd = spec.synth_state_dict(cfg, 3)
+    m = model.Uformer(img_size=128, embed_dim=16, depths=[1] * 9, modulator=True)
+    m.load_state_dict(sd, strict=True)
+    m.load_state_dict({"module." + k: v for k, v in sd.items()}, strict=True)
+    m.load_state_dict({"epoch": 1, "state_dict": {"module." + k: v for k, v in sd.items()}, "optimizer": {}}, strict=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k])
+
+
+def test_weight_packing_matches_reference_arithmetic():
+    g = torch.Generator().manual_seed(0)
+    # downsample: Conv2d(k4,s2,p1) == im2col GEMM with k = (ky*4+kx)*C + c
+    w = torch.randn(16, 8, 4, 4, generator=g)
+    x = torch.randn(1, 8, 8, 8, generator=g)                    # NCHW
+    ref = torch.nn.functional.conv2d(x, w, stride=2, padding=1)
+    cols = torch.nn.functional.unfold(x, 4, padding=1, stride=2)  # (1, C*16, L) with (c,ky,kx) order
+    cols = cols.reshape(1, 8, 16, -1).permute(0, 3, 2, 1).reshape(-1, 16 * 8)  # -> (ky,kx,c)
+    got = (cols @ packing.pack_downsample(w, torch.float32).t()).t().reshape(1, 16, 4, 4)
+    assert (got - ref).abs().max() < 1e-4
+    # upsample: ConvTranspose2d(k2,s2) == GEMM with n = (dy*2+dx)*Cout + co then scatter
+    wu = torch.randn(8, 4, 2, 2, generator=g)
+    xu = torch.randn(1, 8, 3, 3, generator=g)
+    refu = torch.nn.functional.conv_transpose2d(xu, wu, stride=2)
+    y = xu.permute(0, 2, 3, 1).reshape(-1, 8) @ packing.pack_upsample(wu, torch.float32).t()   # (9, 4*4)
+    gotu = y.reshape(3, 3, 2, 2, 4).permute(4, 0, 2, 1, 3).reshape(1, 4, 6, 6)
+    assert (gotu - refu).abs().max() < 1e-5
+    # dense relative-position bias == the reference gather
+    table = torch.randn(225, 3, generator=g)
+    idx = spec.relative_position_index(8)
+    assert torch.equal(packing.rpb_dense(table, idx), O.relative_position_bias(table, idx))
+    # depthwise taps, stem and head layouts
+    wd = torch.randn(6, 1, 3, 3, generator=g)
+    assert torch.equal(packing.pack_dwconv(wd)[4], wd[:, 0, 1, 1])
+    wi = torch.randn(8, 3, 3, 3, generator=g)
+    assert torch.equal(packing.pack_input_proj(wi)[1 * 9 + 2 * 3 + 0], wi[:, 1, 2, 0])
+    wo = torch.randn(3, 16, 3, 3, generator=g)
+    assert torch.equal(packing.pack_output_proj(wo)[2, 1 * 3 + 2], wo[2, :, 1, 2])
+
+
+def test_window_index_closed_form_is_a_permutation():
+    for B, H, W, s in ((2, 16, 24, 4), (1, 8, 8, 0), (3, 32, 16, 4)):
+        idx = O.window_partition_index(B, H, W, 8, s)
+        assert np.array_equal(np.sort(idx), np.arange(B * H * W))
+
+
+def test_shard_batch():
+    for gb, w in ((16, 1), (16, 8), (17, 4), (3, 8), (256, 8)):
+        parts = [ud.shard_batch(gb, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == gb
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in parts]
+        assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,106 @@
+"""ctypes binding of ``libuformer_hip.so`` (C ABI declared in ``include/uformer_hip.h``).
+
+There is NO fallback: if the library is missing or a call fails this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libuformer_hip.so")
+
+UF_F32, UF_BF16 = 0, 1
+
+c_int, c_void_p, c_size_t, c_float_p = C.c_int, C.c_void_p, C.c_size_t, C.c_void_p
+
+
+class BlockParams(C.Structure):
+    """``uf_block_params`` (include/uformer_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "modulator", "rpb_dense", "wqkv", "bqkv", "wproj", "bproj",
+        "norm2_w", "norm2_b", "w1", "b1", "wdw9", "bdw", "w2", "b2")] + [
+        ("shift", C.c_int32), ("heads", C.c_int32)]
+
+
+class ModelDesc(C.Structure):
+    """``uf_model_desc`` (include/uformer_hip.h)."""
+    _fields_ = [
+        ("embed_dim", C.c_int32), ("dd_in", C.c_int32), ("in_chans", C.c_int32),
+        ("depths", C.c_int32 * 9),
+        ("blocks", C.POINTER(BlockParams)),
+        ("in_w27", C.c_void_p), ("in_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+        ("down_w", C.c_void_p * 4), ("down_b", C.c_void_p * 4),
+        ("up_w", C.c_void_p * 4), ("up_b", C.c_void_p * 4),
+    ]
+
+
+P = c_void_p
+I = c_int
+# name -> (restype, argtypes); must list every function declared in include/uformer_hip.h
+SIGNATURES = {
+    "uf_version": (I, []),
+    "uf_last_error": (I, [C.c_char_p, c_size_t]),
+    "uf_timing_enable": (I, [I]),
+    "uf_timing_report": (I, [C.c_char_p, c_size_t]),
+    "uf_window_partition": (I, [P, P, I, I, I, I, I, I, P]),
+    "uf_window_reverse": (I, [P, P, I, I, I, I, I, I, P]),
+    "uf_shift_mask": (I, [P, I, I, I, P]),
+    "uf_layernorm_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "uf_linear_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "uf_qkv_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "uf_window_attention_fwd": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
+    "uf_dwconv3x3_gelu_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "uf_block_workspace_bytes": (c_size_t, [I, I, I]),
+    "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
+    "uf_leff_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, I, P, c_size_t, P]),
+    "uf_lewin_block_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
+    "uf_downsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "uf_upsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
+    "uf_input_proj_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "uf_output_proj_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+    "uf_uformer_workspace_bytes": (c_size_t, [C.POINTER(ModelDesc), I, I, I, I]),
+    "uf_uformer_fwd": (I, [C.POINTER(ModelDesc), P, P, I, I, I, I, P, c_size_t, P]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class UformerHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise UformerHipError(
+                f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the hot path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if lib.uf_version() != 1:
+            raise UformerHipError(f"ABI version mismatch: library reports {lib.uf_version()}, binding expects 1")
+        _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().uf_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise UformerHipError(f"{what} failed (code {rc}): {last_error()}")

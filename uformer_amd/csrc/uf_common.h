@@ -1,0 +1,123 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) Uformer kernels.
+// wave = 64 lanes, MFMA 16x16 tiles, fp32 accumulate everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/uformer_hip.h"
+
+namespace uf {
+
+// ------------------------------------------------------------------------------------
+// element types.  T = operand/activation type (bf16 or f32), R = residual stream = f32.
+// ------------------------------------------------------------------------------------
+struct bf16 { uint16_t v; };
+typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// exact erf GELU (nn.GELU default; reference model.py:657-660)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 8 operand elements of type T (one MFMA k-slot group per lane)
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+    u32x4 v;  // 8 x bf16
+    __device__ __forceinline__ void zero() { v = u32x4{0, 0, 0, 0}; }
+};
+template <> struct Frag<float> {
+    f32x4 lo, hi;  // 8 x f32
+    __device__ __forceinline__ void zero() { lo = f32x4{0, 0, 0, 0}; hi = lo; }
+};
+
+// D(16x16) += A(16 x 32) * B(32 x 16).  A-frag: lane holds row (lane&15), 8 k-slots of group
+// g = lane>>4; B-frag: lane holds col (lane&15), the SAME 8 k-slots.  Only the pairing of A and
+// B slots matters, so both operand types use one loading pattern.  D: col = lane&15,
+// row = 4*(lane>>4) + reg.
+__device__ __forceinline__ void mma16(f32x4& d, const Frag<bf16>& a, const Frag<bf16>& b) {
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a.v),
+                                                __builtin_bit_cast(mfma_bf16x8, b.v), d, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& d, const Frag<float>& a, const Frag<float>& b) {
+    // exact-f32 MFMA (v_mfma_f32_16x16x4_f32): 8 steps, step j pairs slot j of every lane group.
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[0], b.lo[0], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[1], b.lo[1], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[2], b.lo[2], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[3], b.lo[3], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[0], b.hi[0], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[1], b.hi[1], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[2], b.hi[2], d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[3], b.hi[3], d, 0, 0, 0);
+}
+
+// load 8 consecutive T elements (16 B for bf16, 32 B for f32) into a fragment
+__device__ __forceinline__ void load_frag(Frag<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void load_frag(Frag<float>& f, const float* p) {
+    f.lo = *reinterpret_cast<const f32x4*>(p);
+    f.hi = *reinterpret_cast<const f32x4*>(p + 4);
+}
+
+// store 4 consecutive values as T
+__device__ __forceinline__ void store4(bf16* p, f32x4 v) {
+    u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = o;
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store1(bf16* p, float v) { p->v = f2bf(v); }
+__device__ __forceinline__ void store1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float load1(const bf16* p) { return bf2f(p->v); }
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+
+// window-order row m -> flat token index in (B,H,W) for cyclic shift `shift`
+// (reference model.py:957 roll(-shift) then window_partition :713-714; the inverse mapping
+//  is window_reverse :720,725 then roll(+shift) :980 -- the same index pairs).
+__device__ __forceinline__ int window_row_to_token(int m, int H, int W, int shift) {
+    const int nWc = W >> 3, nW = (H >> 3) * nWc;
+    const int bw = m >> 6, t = m & 63;
+    const int b = bw / nW, wi = bw - b * nW;
+    const int wr = wi / nWc, wc = wi - wr * nWc;
+    int h = (wr << 3) + (t >> 3) + shift; if (h >= H) h -= H;
+    int w = (wc << 3) + (t & 7) + shift;  if (w >= W) w -= W;
+    return (b * H + h) * W + w;
+}
+
+// ------------------------------------------------------------------------------------
+// host side: error reporting
+// ------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// Opt-in timing (uf_timing_enable): brackets one kernel launch with HIP events on its stream and
+// books its algorithmic flops / bytes under `name`.  A no-op (one branch) when disabled.
+bool timing_enabled();
+struct ScopedTimer {
+    ScopedTimer(const char* name, double flops, double bytes, hipStream_t st);
+    ~ScopedTimer();
+    hipStream_t st_;
+    int idx_;
+};
+
+#define UF_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::uf::set_error(__VA_ARGS__);    \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+inline size_t dtype_size(int dt) { return dt == UF_BF16 ? 2 : 4; }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace uf

@@ -1,0 +1,109 @@
+// Error plumbing and version of libuformer_hip.
+#include <stdarg.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "uf_common.h"
+
+namespace uf {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: kernel launch failed: %s", what, hipGetErrorString(e));
+        return UF_ERR_LAUNCH;
+    }
+    return UF_OK;
+}
+
+// ---- opt-in per-kernel-class timing with HIP events on the launch stream -------------------
+namespace {
+struct Rec { hipEvent_t a, b; int cls; };
+struct Cls { std::string name; double flops = 0, bytes = 0; long launches = 0; };
+bool g_timing = false;
+std::mutex g_mu;
+std::vector<Rec> g_recs;
+std::vector<Cls> g_cls;
+}  // namespace
+
+bool timing_enabled() { return g_timing; }
+
+ScopedTimer::ScopedTimer(const char* name, double flops, double bytes, hipStream_t st) : st_(st), idx_(-1) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    int c = -1;
+    for (size_t i = 0; i < g_cls.size(); ++i)
+        if (g_cls[i].name == name) { c = (int)i; break; }
+    if (c < 0) { g_cls.push_back(Cls{name}); c = (int)g_cls.size() - 1; }
+    g_cls[c].flops += flops; g_cls[c].bytes += bytes; g_cls[c].launches += 1;
+    Rec r; r.cls = c;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    hipEventRecord(r.a, st_);
+    g_recs.push_back(r);
+    idx_ = (int)g_recs.size() - 1;
+}
+
+ScopedTimer::~ScopedTimer() {
+    if (idx_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (idx_ < (int)g_recs.size()) hipEventRecord(g_recs[idx_].b, st_);
+}
+
+}  // namespace uf
+
+extern "C" int uf_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(uf::g_mu);
+    uf::g_timing = on != 0;
+    return UF_OK;
+}
+
+extern "C" int uf_timing_report(char* json, size_t n) {
+    using namespace uf;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<double> ms(g_cls.size(), 0.0);
+    for (auto& r : g_recs) {
+        float t = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) ms[r.cls] += t;
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    std::string out = "[";
+    for (size_t i = 0; i < g_cls.size(); ++i) {
+        char buf[320];
+        snprintf(buf, sizeof(buf), "%s{\"kernel\":\"%s\",\"launches\":%ld,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}",
+                 i ? "," : "", g_cls[i].name.c_str(), g_cls[i].launches, ms[i], g_cls[i].flops, g_cls[i].bytes);
+        out += buf;
+    }
+    out += "]";
+    g_recs.clear();
+    g_cls.clear();
+    if (json && n) {
+        const size_t c = out.size() < n - 1 ? out.size() : n - 1;
+        memcpy(json, out.data(), c);
+        json[c] = 0;
+    }
+    return (int)out.size();
+}
+
+extern "C" int uf_version(void) { return UF_ABI_VERSION; }
+
+extern "C" int uf_last_error(char* buf, size_t n) {
+    const size_t len = strlen(uf::g_err);
+    if (buf && n) {
+        const size_t c = len < n - 1 ? len : n - 1;
+        memcpy(buf, uf::g_err, c);
+        buf[c] = 0;
+    }
+    return (int)len;
+}

@@ -1,0 +1,374 @@
+// HBM-bound kernels of the LeWin block: index-only window ops, LayerNorm(+roll+partition+
+// modulator), the LeFF depthwise 3x3 + GELU stencil, and the 3-channel stem/head convolutions.
+// All of them move 16 bytes per lane per access and keep consecutive lanes on consecutive
+// addresses of the channel-last token layout.
+#include "uf_internal.h"
+
+namespace uf {
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// a1-a3: window_partition / window_reverse with the cyclic shift folded into the index.
+// One thread moves one 16-byte chunk of a token row (bit-exact copy).
+// ---------------------------------------------------------------------------------------
+template <bool REVERSE>
+__global__ void window_copy_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int rows, int chunks_per_row,
+                                   int H, int W, int shift) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * chunks_per_row) return;
+    const int m = (int)(idx / chunks_per_row), c = (int)(idx - (long long)m * chunks_per_row);
+    const int tok = window_row_to_token(m, H, W, shift);
+    if (REVERSE) dst[(size_t)tok * chunks_per_row + c] = src[(size_t)m * chunks_per_row + c];
+    else dst[(size_t)m * chunks_per_row + c] = src[(size_t)tok * chunks_per_row + c];
+}
+
+// generic fall-back for rows that are not a multiple of 16 bytes (element granularity)
+template <bool REVERSE, typename E>
+__global__ void window_copy_elem_kernel(const E* __restrict__ src, E* __restrict__ dst, int rows, int C, int H, int W, int shift) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)rows * C) return;
+    const int m = (int)(idx / C), c = (int)(idx - (long long)m * C);
+    const int tok = window_row_to_token(m, H, W, shift);
+    if (REVERSE) dst[(size_t)tok * C + c] = src[(size_t)m * C + c];
+    else dst[(size_t)m * C + c] = src[(size_t)tok * C + c];
+}
+
+// ---------------------------------------------------------------------------------------
+// a5/a6: LayerNorm over C (+ roll + partition gather + modulator add), f32 in, T out.
+// LPR lanes share one row, each lane owns C/LPR values (4 or 8) in registers; two-pass
+// (mean, then centred variance) like ATen's native_layer_norm; xor-shuffle reductions.
+// ---------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, const float* __restrict__ modulator,
+                                                        T* __restrict__ out, int rows, int H, int W, int windowed, int shift) {
+    constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;  // lanes per row
+    constexpr int V4 = C / (4 * LPR);                 // float4 per lane (1 or 2)
+    constexpr int RPB = 256 / LPR;                    // rows per block
+    const int sub = threadIdx.x % LPR;
+    const int m = blockIdx.x * RPB + threadIdx.x / LPR;
+    const bool live = m < rows;
+    const int src = live ? (windowed ? window_row_to_token(m, H, W, shift) : m) : 0;
+    f32x4 v[V4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i] = live ? *reinterpret_cast<const f32x4*>(x + (size_t)src * ld_x + (i * LPR + sub) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum * (1.0f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        v[i] -= mean;
+        sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+    }
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        const int c = (i * LPR + sub) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 y = v[i] * rstd * g + b;
+        if (modulator) y += *reinterpret_cast<const f32x4*>(modulator + (size_t)(m & 63) * C + c);  // model.py:966-969
+        store4(out + (size_t)m * C + c, y);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a10: depthwise 3x3 (zero pad 1) + bias + erf-GELU on [B][H][W][C] (LeFF, model.py:659-660).
+// One thread = one pixel x VEC channels (16 bytes of T); fp32 accumulate.
+// ---------------------------------------------------------------------------------------
+template <typename T> struct Vec16;
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16* p, float* f) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float* f) {
+        u32x4 r = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+        *reinterpret_cast<u32x4*>(p) = r;
+    }
+};
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* f) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+        f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* f) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict__ x, const float* __restrict__ w9,
+                                                             const float* __restrict__ bias, T* __restrict__ out, int B, int H,
+                                                             int W, int C) {
+    constexpr int N = Vec16<T>::N;
+    const int cv = C / N;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * H * W * cv) return;
+    const int c = (int)(idx % cv) * N;
+    const long long pix = idx / cv;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int b = (int)(pix / ((long long)W * H));
+    float acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = bias[c + i];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yh + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = xw + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            float f[N];
+            Vec16<T>::load(x + ((size_t)(b * H + iy) * W + ix) * C + c, f);
+            const float* wp = w9 + (ky * 3 + kx) * C + c;
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[i] = fmaf(f[i], wp[i], acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = gelu_erf(acc[i]);
+    Vec16<T>::store(out + (size_t)pix * C + c, acc);
+}
+
+// ---------------------------------------------------------------------------------------
+// a14: InputProj conv3x3(Cin->E) + LeakyReLU(0.01), NCHW image -> token rows.
+// One thread = one pixel x 4 output channels.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ img, const float* __restrict__ w27,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int ld_o, int B,
+                                                         int Cin, int H, int W, int E) {
+    const int eg = E / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * H * W * eg) return;
+    const int e = (int)(idx % eg) * 4;
+    const long long pix = idx / eg;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    f32x4 acc = *reinterpret_cast<const f32x4*>(bias + e);
+    for (int ci = 0; ci < Cin; ++ci) {
+        const float* plane = img + ((size_t)b * Cin + ci) * H * W;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = yh + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = xw + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float v = plane[(size_t)iy * W + ix];
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w27 + (size_t)(ci * 9 + ky * 3 + kx) * E + e);
+                acc += v * wv;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = acc[i] >= 0.f ? acc[i] : 0.01f * acc[i];
+    *reinterpret_cast<f32x4*>(out + (size_t)pix * ld_o + e) = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// a14: OutputProj conv3x3(C2->3) (+ global residual), token rows -> NCHW image.
+// LPP = C2/4 lanes share one pixel, each owning 4 input channels; xor-shuffle reduction.
+// ---------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void output_proj_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, const float* __restrict__ img,
+                                                          float* __restrict__ out, int B, int H, int W, int add_img) {
+    constexpr int C2 = LPP * 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int sub = (int)(idx % LPP);
+    long long pix = idx / LPP;
+    const bool live = pix < (long long)B * H * W;
+    if (!live) pix = 0;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H), b = (int)(pix / ((long long)W * H));
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yh + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = xw + kx - 1;
+            if (ix < 0 || ix >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * ld_x + sub * 4);
+            const int tap = ky * 3 + kx;
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (size_t)(0 * 9 + tap) * C2 + sub * 4);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + (size_t)(1 * 9 + tap) * C2 + sub * 4);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(w + (size_t)(2 * 9 + tap) * C2 + sub * 4);
+            a0 += (v[0] * w0[0] + v[1] * w0[1]) + (v[2] * w0[2] + v[3] * w0[3]);
+            a1 += (v[0] * w1[0] + v[1] * w1[1]) + (v[2] * w1[2] + v[3] * w1[3]);
+            a2 += (v[0] * w2[0] + v[1] * w2[1]) + (v[2] * w2[2] + v[3] * w2[3]);
+        }
+    }
+#pragma unroll
+    for (int o = LPP >> 1; o > 0; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+        a2 += __shfl_xor(a2, o);
+    }
+    if (live && sub < 3) {
+        const float a = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
+        const size_t o = ((size_t)b * 3 + sub) * H * W + (size_t)yh * W + xw;
+        float r = a + bias[sub];
+        if (add_img) r += img[o];  // return x + y (model.py:1305)
+        out[o] = r;
+    }
+}
+
+}  // namespace
+
+int launch_layernorm(const float* x, int ld_x, const float* gamma, const float* beta, const float* modulator, void* out,
+                     int rows, int H, int W, int C, int windowed, int shift, uf_dtype dtype, hipStream_t st) {
+    ScopedTimer tm(windowed ? "layernorm_window" : "layernorm", 8.0 * rows * C, (double)rows * C * (4 + dtype_size(dtype)), st);
+#define UF_LN_CASE(CV)                                                                                                  \
+    case CV: {                                                                                                          \
+        constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64;                                                              \
+        constexpr int RPB = 256 / LPR;                                                                                  \
+        dim3 grid((rows + RPB - 1) / RPB);                                                                              \
+        if (dtype == UF_BF16)                                                                                           \
+            hipLaunchKernelGGL((layernorm_kernel<bf16, CV>), grid, dim3(256), 0, st, x, ld_x, gamma, beta, modulator,   \
+                               (bf16*)out, rows, H, W, windowed, shift);                                                \
+        else                                                                                                            \
+            hipLaunchKernelGGL((layernorm_kernel<float, CV>), grid, dim3(256), 0, st, x, ld_x, gamma, beta, modulator,  \
+                               (float*)out, rows, H, W, windowed, shift);                                               \
+        break;                                                                                                          \
+    }
+    switch (C) {
+        UF_LN_CASE(16)
+        UF_LN_CASE(32)
+        UF_LN_CASE(64)
+        UF_LN_CASE(128)
+        UF_LN_CASE(256)
+        UF_LN_CASE(512)
+        UF_LN_CASE(1024)
+        default:
+            set_error("layernorm: C=%d unsupported (16,32,64,128,256,512,1024)", C);
+            return UF_ERR_UNSUPPORTED;
+    }
+#undef UF_LN_CASE
+    return check_launch("layernorm");
+}
+
+}  // namespace uf
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+using namespace uf;
+
+static int window_copy(const void* src, void* dst, int B, int H, int W, int C, int shift, int elem_bytes, bool reverse,
+                       void* stream) {
+    UF_REQUIRE(src && dst, UF_ERR_NULL, "window op: null pointer");
+    UF_REQUIRE(B > 0 && C > 0 && H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8, UF_ERR_SHAPE, "window op: B=%d H=%d W=%d C=%d", B, H, W, C);
+    UF_REQUIRE(shift >= 0 && shift < 8, UF_ERR_SHAPE, "window op: shift=%d", shift);
+    UF_REQUIRE(elem_bytes == 2 || elem_bytes == 4, UF_ERR_UNSUPPORTED, "window op: elem_bytes=%d (2 or 4)", elem_bytes);
+    const int rows = B * H * W;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t row_bytes = (size_t)C * elem_bytes;
+    if (row_bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) {
+        const int cpr = (int)(row_bytes / 16);
+        const long long n = (long long)rows * cpr;
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (reverse) hipLaunchKernelGGL(window_copy_kernel<true>, grid, dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, rows, cpr, H, W, shift);
+        else hipLaunchKernelGGL(window_copy_kernel<false>, grid, dim3(256), 0, st, (const u32x4*)src, (u32x4*)dst, rows, cpr, H, W, shift);
+    } else {
+        const long long n = (long long)rows * C;
+        dim3 grid((unsigned)((n + 255) / 256));
+        if (elem_bytes == 4) {
+            if (reverse) hipLaunchKernelGGL((window_copy_elem_kernel<true, uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, C, H, W, shift);
+            else hipLaunchKernelGGL((window_copy_elem_kernel<false, uint32_t>), grid, dim3(256), 0, st, (const uint32_t*)src, (uint32_t*)dst, rows, C, H, W, shift);
+        } else {
+            if (reverse) hipLaunchKernelGGL((window_copy_elem_kernel<true, uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, rows, C, H, W, shift);
+            else hipLaunchKernelGGL((window_copy_elem_kernel<false, uint16_t>), grid, dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, rows, C, H, W, shift);
+        }
+    }
+    return check_launch("window op");
+}
+
+extern "C" int uf_window_partition(const void* x, void* out, int B, int H, int W, int C, int shift, int elem_bytes, void* stream) {
+    return window_copy(x, out, B, H, W, C, shift, elem_bytes, false, stream);
+}
+extern "C" int uf_window_reverse(const void* windows, void* out, int B, int H, int W, int C, int shift, int elem_bytes, void* stream) {
+    return window_copy(windows, out, B, H, W, C, shift, elem_bytes, true, stream);
+}
+
+extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, const float* beta, const float* modulator,
+                                void* out, int B, int H, int W, int C, int windowed, int shift, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && gamma && beta && out, UF_ERR_NULL, "uf_layernorm_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0, UF_ERR_SHAPE, "uf_layernorm_fwd: B=%d H=%d W=%d", B, H, W);
+    UF_REQUIRE(!windowed || (H % 8 == 0 && W % 8 == 0), UF_ERR_SHAPE, "uf_layernorm_fwd: windowed needs H,W multiples of 8");
+    UF_REQUIRE(ld_x >= C && ld_x % 4 == 0, UF_ERR_ALIGN, "uf_layernorm_fwd: ld_x=%d", ld_x);
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_layernorm_fwd: dtype %d", (int)dtype);
+    return launch_layernorm(x, ld_x, gamma, beta, modulator, out, B * H * W, H, W, C, windowed, shift, dtype, (hipStream_t)stream);
+}
+
+extern "C" int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C,
+                                     uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w9 && bias && out, UF_ERR_NULL, "uf_dwconv3x3_gelu_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    ScopedTimer tm("dwconv3x3_gelu", 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), st);
+    if (dtype == UF_BF16) {
+        UF_REQUIRE(C % 8 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 8", C);
+        const long long n = (long long)B * H * W * (C / 8);
+        hipLaunchKernelGGL(dwconv3x3_gelu_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
+    } else if (dtype == UF_F32) {
+        UF_REQUIRE(C % 4 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 4", C);
+        const long long n = (long long)B * H * W * (C / 4);
+        hipLaunchKernelGGL(dwconv3x3_gelu_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
+    } else {
+        set_error("uf_dwconv3x3_gelu_fwd: dtype %d", (int)dtype);
+        return UF_ERR_UNSUPPORTED;
+    }
+    return check_launch("dwconv3x3_gelu");
+}
+
+extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float* bias, float* out, int ld_o, int B, int Cin,
+                                 int H, int W, int E, void* stream) {
+    UF_REQUIRE(img && w27 && bias && out, UF_ERR_NULL, "uf_input_proj_fwd: null pointer");
+    UF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && E % 4 == 0 && ld_o >= E && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_input_proj_fwd: bad shape");
+    const long long n = (long long)B * H * W * (E / 4);
+    ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
+    hipLaunchKernelGGL(input_proj_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
+    return check_launch("input_proj");
+}
+
+extern "C" int uf_output_proj_fwd(const float* x, int ld_x, const float* w, const float* bias, const float* img, float* out,
+                                  int B, int H, int W, int C2, int add_img, void* stream) {
+    UF_REQUIRE(x && w && bias && out && (!add_img || img), UF_ERR_NULL, "uf_output_proj_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && ld_x >= C2 && ld_x % 4 == 0, UF_ERR_SHAPE, "uf_output_proj_fwd: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    const long long pix = (long long)B * H * W;
+    ScopedTimer tm("output_proj", 54.0 * pix * C2, 4.0 * pix * (C2 + 6), st);
+#define UF_OP_CASE(LPPV)                                                                                          \
+    case LPPV * 4: {                                                                                              \
+        const long long n = pix * LPPV;                                                                           \
+        hipLaunchKernelGGL(output_proj_kernel<LPPV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld_x, \
+                           w, bias, img, out, B, H, W, add_img);                                                  \
+        break;                                                                                                    \
+    }
+    switch (C2) {
+        UF_OP_CASE(4)
+        UF_OP_CASE(8)
+        UF_OP_CASE(16)
+        UF_OP_CASE(32)
+        default:
+            set_error("uf_output_proj_fwd: C2=%d unsupported (16,32,64,128)", C2);
+            return UF_ERR_UNSUPPORTED;
+    }
+#undef UF_OP_CASE
+    return check_launch("output_proj");
+}

@@ -1,0 +1,34 @@
+// Internal (non-ABI) launch functions shared between the translation units of libuformer_hip.
+#pragma once
+#include "uf_common.h"
+
+namespace uf {
+
+enum ALoad { A_PLAIN = 0, A_FROM_R = 1, A_CONV_DOWN = 2 };
+enum Epi {
+    E_STORE_T = 0,      // out T[m][n] = acc + bias
+    E_STORE_T_GELU = 1, // out T[m][n] = gelu(acc + bias)
+    E_QKV = 2,          // split into q (scaled) / k / v^T per (window, head)
+    E_RES_WINREV = 3,   // out f32[tok(m)][n] = resid[tok(m)][n] + acc + bias  (window_reverse + unroll)
+    E_RES = 4,          // out f32[m][n] = resid[m][n] + acc + bias
+    E_STORE_R = 5,      // out f32[m][n] = acc + bias
+    E_UPSAMPLE = 6      // ConvTranspose2d k2 s2 scatter into (2H,2W)
+};
+
+struct GemmParams {
+    const void* A; int lda;     // A_PLAIN: T[M][lda]; A_FROM_R / A_CONV_DOWN: f32 rows of stride lda
+    const void* W;              // T[N][K]
+    const float* bias;
+    int M, N, K;
+    int H, W_, C;               // geometry: conv-down input (H,W,C); winrev (H,W); upsample input (H,W)
+    int shift;
+    void* out; int ldo;
+    const float* resid; int ldr;
+    void* q; void* k; void* vt; int heads, hd; float qscale;
+    int Cout;
+};
+
+// dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.
+int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream);
+
+}  // namespace uf

@@ -1,0 +1,265 @@
+// Host-side drivers: the LeWin block (attention half + LeFF half), the samplers and the whole
+// Uformer forward, expressed as launches of the kernels in uf_gemm / uf_attn / uf_elementwise.
+// Mirrors LeWinTransformerBlock.forward (model.py:908-989), BasicUformerLayer.forward
+// (:1054-1060) and Uformer.forward (:1269-1305) of the reference.
+#include "uf_internal.h"
+
+namespace uf {
+
+int launch_layernorm(const float* x, int ld_x, const float* gamma, const float* beta, const float* modulator, void* out,
+                     int rows, int H, int W, int C, int windowed, int shift, uf_dtype dtype, hipStream_t st);
+
+namespace {
+
+struct BlockWs {
+    char* a;   // T[M][C]   : LN output / attention output
+    char* h1;  // T[M][4C]  : q,k,v^T (first 3*M*C) / LeFF hidden after fc1
+    char* h2;  // T[M][4C]  : LeFF hidden after the depthwise conv
+};
+
+size_t block_ws_bytes(size_t M, size_t C, uf_dtype dtype) {
+    const size_t sz = dtype_size(dtype);
+    return align_up(M * C * sz, 256) + 2 * align_up(M * 4 * C * sz, 256);
+}
+
+int carve(BlockWs& w, void* ws, size_t ws_bytes, size_t M, size_t C, uf_dtype dtype) {
+    UF_REQUIRE(ws, UF_ERR_NULL, "workspace is null");
+    UF_REQUIRE(((uintptr_t)ws % 256) == 0, UF_ERR_ALIGN, "workspace must be 256-byte aligned");
+    const size_t need = block_ws_bytes(M, C, dtype);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    const size_t sz = dtype_size(dtype);
+    w.a = (char*)ws;
+    w.h1 = w.a + align_up(M * C * sz, 256);
+    w.h2 = w.h1 + align_up(M * 4 * C * sz, 256);
+    return UF_OK;
+}
+
+int check_block_args(const uf_block_params* p, const float* x, int ld, int B, int H, int W, int C, uf_dtype dtype) {
+    UF_REQUIRE(p && x, UF_ERR_NULL, "block: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "block: dtype %d", (int)dtype);
+    UF_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, UF_ERR_SHAPE, "block: B=%d H=%d W=%d (H,W multiples of 8)", B, H, W);
+    UF_REQUIRE(C >= 16 && C % 16 == 0 && ld >= C && ld % 4 == 0, UF_ERR_SHAPE, "block: C=%d ld=%d", C, ld);
+    UF_REQUIRE(p->heads > 0 && C % p->heads == 0, UF_ERR_SHAPE, "block: C=%d heads=%d", C, p->heads);
+    UF_REQUIRE(p->shift == 0 || p->shift == 4, UF_ERR_UNSUPPORTED, "block: shift=%d (0 or 4)", p->shift);
+    UF_REQUIRE((long long)B * H * W * 4LL * C < 0x7fffffffLL * 4, UF_ERR_SHAPE, "block: tensor too large for 32-bit row indexing");
+    return UF_OK;
+}
+
+int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask,
+              uf_dtype dtype, const BlockWs& w, hipStream_t st) {
+    const int M = B * H * W;
+    const size_t sz = dtype_size(dtype);
+    const int heads = p->heads, hd = C / heads;
+    // LN1 -> roll -> partition -> + modulator           (model.py:952-969)
+    int rc = launch_layernorm(x, ld, p->norm1_w, p->norm1_b, p->modulator, w.a, M, H, W, C, 1, p->shift, dtype, st);
+    if (rc) return rc;
+    // q,k,v projections                                 (model.py:431-442, :497)
+    char* q = w.h1;
+    char* k = q + (size_t)M * C * sz;
+    char* vt = k + (size_t)M * C * sz;
+    rc = uf_qkv_fwd(w.a, p->wqkv, p->bqkv, q, k, vt, M, C, heads, dtype, st);
+    if (rc) return rc;
+    // softmax(q k^T + bias + mask) v                    (model.py:498-519)
+    rc = uf_window_attention_fwd(q, k, vt, p->rpb_dense, user_mask, n_mask, w.a, M / 64, heads, hd, H, W, p->shift, dtype, st);
+    if (rc) return rc;
+    // proj, window_reverse, roll back, + shortcut       (model.py:520, :975-986)
+    GemmParams g{};
+    g.A = w.a; g.lda = C; g.W = p->wproj; g.bias = p->bproj; g.M = M; g.N = C; g.K = C;
+    g.H = H; g.W_ = W; g.shift = p->shift;
+    g.out = x; g.ldo = ld; g.resid = x; g.ldr = ld;
+    return launch_gemm(g, A_PLAIN, E_RES_WINREV, dtype, st);
+}
+
+int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
+              hipStream_t st) {
+    const int M = B * H * W;
+    // LN2                                                (model.py:987)
+    int rc = launch_layernorm(x, ld, p->norm2_w, p->norm2_b, nullptr, w.a, M, H, W, C, 0, 0, dtype, st);
+    if (rc) return rc;
+    // linear1 + GELU                                     (model.py:657-658, :671)
+    rc = uf_linear_fwd(w.a, p->w1, p->b1, w.h1, M, 4 * C, C, 1, dtype, st);
+    if (rc) return rc;
+    // depthwise 3x3 + GELU over the whole H x W map      (model.py:659-660, :674-680)
+    rc = uf_dwconv3x3_gelu_fwd(w.h1, p->wdw9, p->bdw, w.h2, B, H, W, 4 * C, dtype, st);
+    if (rc) return rc;
+    // linear2 + residual                                 (model.py:661, :682, :987)
+    GemmParams g{};
+    g.A = w.h2; g.lda = 4 * C; g.W = p->w2; g.bias = p->b2; g.M = M; g.N = C; g.K = 4 * C;
+    g.out = x; g.ldo = ld; g.resid = x; g.ldr = ld;
+    return launch_gemm(g, A_PLAIN, E_RES, dtype, st);
+}
+
+}  // namespace
+}  // namespace uf
+
+using namespace uf;
+
+extern "C" size_t uf_block_workspace_bytes(int M, int C, uf_dtype dtype) {
+    if (M <= 0 || C <= 0) return 0;
+    return block_ws_bytes((size_t)M, (size_t)C, dtype);
+}
+
+extern "C" int uf_lewin_attn_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                                 const float* user_mask, int n_mask, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_block_args(p, x, ld, B, H, W, C, dtype);
+    if (rc) return rc;
+    BlockWs w;
+    rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
+    if (rc) return rc;
+    return attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream);
+}
+
+extern "C" int uf_leff_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* ws,
+                           size_t ws_bytes, void* stream) {
+    int rc = check_block_args(p, x, ld, B, H, W, C, dtype);
+    if (rc) return rc;
+    BlockWs w;
+    rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
+    if (rc) return rc;
+    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream);
+}
+
+extern "C" int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                                  const float* user_mask, int n_mask, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_block_args(p, x, ld, B, H, W, C, dtype);
+    if (rc) return rc;
+    BlockWs w;
+    rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
+    if (rc) return rc;
+    rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream);
+    if (rc) return rc;
+    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream);
+}
+
+extern "C" int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B,
+                                 int H, int W, int C, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w && bias && out, UF_ERR_NULL, "uf_downsample_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, UF_ERR_SHAPE, "uf_downsample_fwd: H=%d W=%d", H, W);
+    UF_REQUIRE(ld_x >= C && ld_o >= 2 * C && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_downsample_fwd: ld_x=%d ld_o=%d C=%d", ld_x, ld_o, C);
+    GemmParams g{};
+    g.A = x; g.lda = ld_x; g.W = w; g.bias = bias; g.M = B * (H / 2) * (W / 2); g.N = 2 * C; g.K = 16 * C;
+    g.H = H; g.W_ = W; g.C = C; g.out = out; g.ldo = ld_o;
+    return launch_gemm(g, A_CONV_DOWN, E_STORE_R, dtype, (hipStream_t)stream);
+}
+
+extern "C" int uf_upsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B, int H,
+                               int W, int Cin, int Cout, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w && bias && out, UF_ERR_NULL, "uf_upsample_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && Cout % 4 == 0, UF_ERR_SHAPE, "uf_upsample_fwd: bad shape");
+    UF_REQUIRE(ld_x >= Cin && ld_o >= Cout && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_upsample_fwd: ld_x=%d ld_o=%d", ld_x, ld_o);
+    GemmParams g{};
+    g.A = x; g.lda = ld_x; g.W = w; g.bias = bias; g.M = B * H * W; g.N = 4 * Cout; g.K = Cin;
+    g.H = H; g.W_ = W; g.Cout = Cout; g.out = out; g.ldo = ld_o;
+    return launch_gemm(g, A_FROM_R, E_UPSAMPLE, dtype, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// whole model
+// ------------------------------------------------------------------------------------------
+namespace {
+struct Plan {
+    int C[9];        // block width per stage
+    int res[9];      // H (=W) per stage
+    size_t M[9];     // tokens per stage
+    size_t off_D[4]; // byte offsets of the decoder concat buffers D0..D3 (f32 [M][2*Cskip])
+    size_t off_P;    // bottleneck stream
+    size_t off_blk;  // block scratch
+    size_t blk_bytes;
+    size_t total;
+};
+
+int make_plan(Plan& pl, const uf_model_desc* d, int B, int H, int W, uf_dtype dtype) {
+    UF_REQUIRE(d, UF_ERR_NULL, "model desc is null");
+    UF_REQUIRE(H == W, UF_ERR_SHAPE, "Uformer needs square inputs (reference takes sqrt(L), model.py:910-911): H=%d W=%d", H, W);
+    UF_REQUIRE(H % 128 == 0 && H > 0, UF_ERR_SHAPE, "H=W=%d must be a multiple of 128 (4 downsamplings x window 8)", H);
+    UF_REQUIRE(B > 0, UF_ERR_SHAPE, "B=%d", B);
+    UF_REQUIRE(d->embed_dim >= 16 && d->embed_dim % 16 == 0, UF_ERR_SHAPE, "embed_dim=%d must be a multiple of 16", d->embed_dim);
+    const int e = d->embed_dim;
+    const int mult[9] = {1, 2, 4, 8, 16, 16, 8, 4, 2};
+    const int div[9] = {1, 2, 4, 8, 16, 8, 4, 2, 1};
+    size_t blk = 0;
+    for (int s = 0; s < 9; ++s) {
+        pl.C[s] = e * mult[s];
+        pl.res[s] = H / div[s];
+        pl.M[s] = (size_t)B * pl.res[s] * pl.res[s];
+        const size_t b = block_ws_bytes(pl.M[s], pl.C[s], dtype);
+        if (b > blk) blk = b;
+    }
+    size_t off = 0;
+    for (int k = 0; k < 4; ++k) {  // D_k lives at decoder stage 5+k: rows M[5+k], width C[5+k]
+        pl.off_D[k] = off;
+        off += align_up(pl.M[5 + k] * pl.C[5 + k] * sizeof(float), 256);
+    }
+    pl.off_P = off;
+    off += align_up(pl.M[4] * pl.C[4] * sizeof(float), 256);
+    pl.off_blk = off;
+    pl.blk_bytes = blk;
+    pl.total = off + blk;
+    return UF_OK;
+}
+}  // namespace
+
+extern "C" size_t uf_uformer_workspace_bytes(const uf_model_desc* d, int B, int H, int W, uf_dtype dtype) {
+    Plan pl;
+    if (make_plan(pl, d, B, H, W, dtype) != UF_OK) return 0;
+    return pl.total;
+}
+
+extern "C" int uf_uformer_fwd(const uf_model_desc* d, const float* img, float* out, int B, int H, int W, uf_dtype dtype,
+                              void* ws, size_t ws_bytes, void* stream) {
+    Plan pl;
+    int rc = make_plan(pl, d, B, H, W, dtype);
+    if (rc) return rc;
+    UF_REQUIRE(img && out && ws && d->blocks, UF_ERR_NULL, "uf_uformer_fwd: null pointer");
+    UF_REQUIRE(((uintptr_t)ws % 256) == 0, UF_ERR_ALIGN, "uf_uformer_fwd: workspace must be 256-byte aligned");
+    UF_REQUIRE(ws_bytes >= pl.total, UF_ERR_WORKSPACE, "uf_uformer_fwd: workspace too small: %zu < %zu", ws_bytes, pl.total);
+    UF_REQUIRE(d->in_chans == 3, UF_ERR_UNSUPPORTED, "uf_uformer_fwd: in_chans=%d (3 supported)", d->in_chans);
+    hipStream_t st = (hipStream_t)stream;
+    char* base = (char*)ws;
+    float* D[4];
+    for (int k = 0; k < 4; ++k) D[k] = (float*)(base + pl.off_D[k]);
+    float* P = (float*)(base + pl.off_P);
+    void* bws = base + pl.off_blk;
+
+    // stream of encoder stage s lives in the SECOND half of the concat buffer of decoder stage
+    // 8-s (torch.cat([up, skip], -1), model.py:1288): no concat copy is ever made.
+    auto enc_view = [&](int s, float*& ptr, int& ld) {
+        ptr = D[3 - s] + pl.C[s];
+        ld = 2 * pl.C[s];
+    };
+    const uf_block_params* blk = d->blocks;
+    auto run_stage = [&](int s, float* x, int ld) -> int {
+        for (int i = 0; i < d->depths[s]; ++i, ++blk) {
+            int r = uf_lewin_block_fwd(blk, x, ld, B, pl.res[s], pl.res[s], pl.C[s], nullptr, 0, dtype, bws, pl.blk_bytes, st);
+            if (r) return r;
+        }
+        return UF_OK;
+    };
+
+    float* x; int ld;
+    enc_view(0, x, ld);
+    rc = uf_input_proj_fwd(img, d->in_w27, d->in_b, x, ld, B, d->dd_in, H, W, d->embed_dim, st);  // model.py:1271
+    if (rc) return rc;
+    for (int s = 0; s < 4; ++s) {  // encoder, model.py:1274-1281
+        rc = run_stage(s, x, ld);
+        if (rc) return rc;
+        float* nx; int nld;
+        if (s < 3) enc_view(s + 1, nx, nld); else { nx = P; nld = pl.C[4]; }
+        rc = uf_downsample_fwd(x, ld, d->down_w[s], d->down_b[s], nx, nld, B, pl.res[s], pl.res[s], pl.C[s], dtype, st);
+        if (rc) return rc;
+        x = nx; ld = nld;
+    }
+    rc = run_stage(4, x, ld);  // bottleneck, model.py:1284
+    if (rc) return rc;
+    for (int k = 0; k < 4; ++k) {  // decoder, model.py:1287-1301
+        const int s = 5 + k;
+        const int cin = pl.C[s - 1], cout = pl.C[s] / 2;
+        rc = uf_upsample_fwd(x, ld, d->up_w[k], d->up_b[k], D[k], pl.C[s], B, pl.res[s - 1], pl.res[s - 1], cin, cout, dtype, st);
+        if (rc) return rc;
+        x = D[k]; ld = pl.C[s];
+        rc = run_stage(s, x, ld);
+        if (rc) return rc;
+    }
+    // output projection + global residual, model.py:1304-1305
+    return uf_output_proj_fwd(x, ld, d->out_w, d->out_b, img, out, B, H, W, pl.C[8], d->dd_in == 3 ? 1 : 0, st);
+}

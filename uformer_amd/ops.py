@@ -1,0 +1,234 @@
+"""Thin torch-tensor wrappers over the C ABI (``include/uformer_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every wrapper extracts
+raw pointers and calls ``libuformer_hip.so``.  No op has a CPU or eager fallback -- CPU tensors
+raise.  Names follow the reference functions they replace (model.py:704-726 etc.).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import UF_BF16, UF_F32, UformerHipError
+
+Tensor = torch.Tensor
+
+
+def uf_dtype(dtype) -> int:
+    if dtype in (UF_F32, UF_BF16) and not isinstance(dtype, torch.dtype):
+        return int(dtype)
+    if dtype == torch.float32:
+        return UF_F32
+    if dtype == torch.bfloat16:
+        return UF_BF16
+    raise UformerHipError(f"unsupported operand dtype {dtype} (torch.float32 or torch.bfloat16)")
+
+
+def torch_dtype(dt: int) -> torch.dtype:
+    return torch.bfloat16 if dt == UF_BF16 else torch.float32
+
+
+def _dev(*ts: Tensor) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise UformerHipError("uformer_amd ops run on the GPU only (tensor is on %s); there is no CPU path" % t.device)
+        if dev is not None and t.device != dev:
+            raise UformerHipError("tensors on different devices")
+        dev = t.device
+    return dev
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t: Tensor, dtype: Optional[torch.dtype] = None) -> Tensor:
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# a1-a4 index ops
+# ---------------------------------------------------------------------------------------
+def window_partition(x: Tensor, win_size: int = 8, shift: int = 0) -> Tensor:
+    """(B,H,W,C) -> (B*nW, 8, 8, C).  model.py:704-715; ``shift`` folds torch.roll (:957)."""
+    if win_size != 8:
+        raise UformerHipError("win_size must be 8")
+    _dev(x)
+    B, H, W, Cc = x.shape
+    x = _c(x)
+    if x.element_size() not in (2, 4):
+        raise UformerHipError("window ops support 2- and 4-byte elements")
+    out = torch.empty((B * (H // 8) * (W // 8), 8, 8, Cc), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_window_partition(_ptr(x), _ptr(out), B, H, W, Cc, shift, x.element_size(), _stream()),
+                   "uf_window_partition")
+    return out
+
+
+def window_reverse(windows: Tensor, win_size: int, H: int, W: int, shift: int = 0) -> Tensor:
+    """(B*nW, 8, 8, C) -> (B,H,W,C).  model.py:717-726; ``shift`` folds the roll back (:980)."""
+    if win_size != 8:
+        raise UformerHipError("win_size must be 8")
+    _dev(windows)
+    windows = _c(windows)
+    Cc = windows.shape[-1]
+    nW = (H // 8) * (W // 8)
+    B = windows.shape[0] // nW
+    out = torch.empty((B, H, W, Cc), dtype=windows.dtype, device=windows.device)
+    with torch.cuda.device(windows.device):
+        _lib.check(_lib.load().uf_window_reverse(_ptr(windows), _ptr(out), B, H, W, Cc, shift, windows.element_size(),
+                                                 _stream()), "uf_window_reverse")
+    return out
+
+
+def shift_mask(H: int, W: int, shift: int, device) -> Tensor:
+    """SW-MSA mask (nW,64,64) in {0,-100}.  model.py:924-942."""
+    out = torch.empty(((H // 8) * (W // 8), 64, 64), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.load().uf_shift_mask(_ptr(out), H, W, shift, _stream()), "uf_shift_mask")
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+# float ops
+# ---------------------------------------------------------------------------------------
+def layernorm(x: Tensor, gamma: Tensor, beta: Tensor, *, B: int, H: int, W: int, dtype, windowed: bool = False,
+              shift: int = 0, modulator: Optional[Tensor] = None) -> Tensor:
+    """x f32 (B*H*W, C) rows -> T (rows, C); optionally roll+partition+modulator (model.py:952-969)."""
+    _dev(x, gamma, beta, modulator)
+    dt = uf_dtype(dtype)
+    x = _c(x, torch.float32)
+    Cc = x.shape[-1]
+    out = torch.empty((B * H * W, Cc), dtype=torch_dtype(dt), device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_layernorm_fwd(_ptr(x), Cc, _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)),
+                                                _ptr(None if modulator is None else _c(modulator, torch.float32)),
+                                                _ptr(out), B, H, W, Cc, int(windowed), shift, dt, _stream()),
+                   "uf_layernorm_fwd")
+    return out
+
+
+def linear(a: Tensor, w: Tensor, bias: Tensor, act: int = 0) -> Tensor:
+    """out = act(a @ w.T + bias); a T(M,K), w T(N,K) -- nn.Linear (model.py:426-427,489,657,661)."""
+    _dev(a, w, bias)
+    dt = uf_dtype(a.dtype)
+    a, w = _c(a), _c(w, a.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_linear_fwd(_ptr(a), _ptr(w), _ptr(_c(bias, torch.float32)), _ptr(out), M, N, K, act, dt,
+                                             _stream()), "uf_linear_fwd")
+    return out
+
+
+def qkv(a: Tensor, wqkv: Tensor, bqkv: Tensor, heads: int):
+    """LinearProjection.forward (model.py:431-442) -> q (scaled), k, v^T per (window, head)."""
+    _dev(a, wqkv, bqkv)
+    dt = uf_dtype(a.dtype)
+    a, wqkv = _c(a), _c(wqkv, a.dtype)
+    M, Cc = a.shape
+    hd = Cc // heads
+    q = torch.empty((M // 64, heads, 64, hd), dtype=a.dtype, device=a.device)
+    k = torch.empty_like(q)
+    vt = torch.empty((M // 64, heads, hd, 64), dtype=a.dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_qkv_fwd(_ptr(a), _ptr(wqkv), _ptr(_c(bqkv, torch.float32)), _ptr(q), _ptr(k), _ptr(vt), M,
+                                          Cc, heads, dt, _stream()), "uf_qkv_fwd")
+    return q, k, vt
+
+
+def window_attention_core(q: Tensor, k: Tensor, vt: Tensor, bias_dense: Tensor, *, H: int, W: int, shift: int = 0,
+                          mask: Optional[Tensor] = None) -> Tensor:
+    """softmax(q k^T + bias + masks) v -> (n_windows*64, C).  model.py:498-519."""
+    _dev(q, k, vt, bias_dense, mask)
+    dt = uf_dtype(q.dtype)
+    nwin, heads, _, hd = q.shape
+    out = torch.empty((nwin * 64, heads * hd), dtype=q.dtype, device=q.device)
+    if mask is not None:
+        mask = _c(mask, torch.float32)
+    with torch.cuda.device(q.device):
+        _lib.check(_lib.load().uf_window_attention_fwd(_ptr(_c(q)), _ptr(_c(k)), _ptr(_c(vt)), _ptr(_c(bias_dense, torch.float32)),
+                                                       _ptr(mask), 0 if mask is None else mask.shape[0], _ptr(out), nwin,
+                                                       heads, hd, H, W, shift, dt, _stream()), "uf_window_attention_fwd")
+    return out
+
+
+def dwconv3x3_gelu(x: Tensor, w9: Tensor, bias: Tensor) -> Tensor:
+    """x T(B,H,W,C) channel-last; w9 f32 (9,C); LeFF dwconv + GELU (model.py:659-660)."""
+    _dev(x, w9, bias)
+    dt = uf_dtype(x.dtype)
+    x = _c(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_dwconv3x3_gelu_fwd(_ptr(x), _ptr(_c(w9, torch.float32)), _ptr(_c(bias, torch.float32)),
+                                                     _ptr(out), B, H, W, Cc, dt, _stream()), "uf_dwconv3x3_gelu_fwd")
+    return out
+
+
+def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int) -> Tensor:
+    """x f32 (B*H*W, C) -> f32 (B*H/2*W/2, 2C).  Downsample.forward model.py:739-746."""
+    _dev(x, w_packed, bias)
+    x = _c(x, torch.float32)
+    Cc = x.shape[-1]
+    out = torch.empty((B * (H // 2) * (W // 2), 2 * Cc), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_downsample_fwd(_ptr(x), Cc, _ptr(_c(w_packed)), _ptr(_c(bias, torch.float32)), _ptr(out),
+                                                 2 * Cc, B, H, W, Cc, uf_dtype(w_packed.dtype), _stream()), "uf_downsample_fwd")
+    return out
+
+
+def upsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int, out: Optional[Tensor] = None,
+             ld_o: Optional[int] = None) -> Tensor:
+    """x f32 (B*H*W, Cin) -> f32 (B*2H*2W, Cout).  Upsample.forward model.py:765-771."""
+    _dev(x, w_packed, bias)
+    x = _c(x, torch.float32)
+    Cin = x.shape[-1]
+    Cout = w_packed.shape[0] // 4
+    if out is None:
+        out = torch.empty((B * 4 * H * W, Cout), dtype=torch.float32, device=x.device)
+        ld_o = Cout
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_upsample_fwd(_ptr(x), Cin, _ptr(_c(w_packed)), _ptr(_c(bias, torch.float32)), _ptr(out), ld_o,
+                                               B, H, W, Cin, Cout, uf_dtype(w_packed.dtype), _stream()), "uf_upsample_fwd")
+    return out
+
+
+def input_proj(img: Tensor, w27: Tensor, bias: Tensor) -> Tensor:
+    """img f32 NCHW -> tokens f32 (B*H*W, E).  InputProj.forward model.py:795-800."""
+    _dev(img, w27, bias)
+    img = _c(img, torch.float32)
+    B, Cin, H, W = img.shape
+    E = w27.shape[1]
+    out = torch.empty((B * H * W, E), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.load().uf_input_proj_fwd(_ptr(img), _ptr(_c(w27, torch.float32)), _ptr(_c(bias, torch.float32)),
+                                                 _ptr(out), E, B, Cin, H, W, E, _stream()), "uf_input_proj_fwd")
+    return out
+
+
+def output_proj(x: Tensor, w: Tensor, bias: Tensor, B: int, H: int, W: int, img: Optional[Tensor] = None) -> Tensor:
+    """tokens f32 (B*H*W, C2) -> f32 NCHW (B,3,H,W) (+ img).  OutputProj.forward model.py:828-836, :1305."""
+    _dev(x, w, bias, img)
+    x = _c(x, torch.float32)
+    C2 = x.shape[-1]
+    out = torch.empty((B, 3, H, W), dtype=torch.float32, device=x.device)
+    if img is not None:
+        img = _c(img, torch.float32)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_output_proj_fwd(_ptr(x), C2, _ptr(_c(w, torch.float32)), _ptr(_c(bias, torch.float32)),
+                                                  _ptr(img), _ptr(out), B, H, W, C2, int(img is not None), _stream()),
+                   "uf_output_proj_fwd")
+    return out

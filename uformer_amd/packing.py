@@ -1,0 +1,115 @@
+"""Weight re-layout from the reference ``state_dict`` to what the kernels read.
+
+Pure tensor reshapes (no arithmetic except the dtype cast of GEMM weights to the operand
+type); runs on whatever device the parameters live on.  Layouts are documented in
+``include/uformer_hip.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List
+
+import torch
+
+from . import _lib
+
+Tensor = torch.Tensor
+
+
+def rpb_dense(table: Tensor, index: Tensor) -> Tensor:
+    """(225,heads) table + (64,64) int64 index -> (heads,64,64) f32.  model.py:500-502."""
+    n = index.shape[0]
+    return table.detach()[index.reshape(-1)].reshape(n, n, -1).permute(2, 0, 1).contiguous().float()
+
+
+def pack_dwconv(w: Tensor) -> Tensor:
+    """(C,1,3,3) -> (9,C) tap-major f32."""
+    return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
+
+
+def pack_downsample(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """Conv2d weight (2C,C,4,4) -> (2C, 16C) with k = (ky*4+kx)*C + c."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous().to(dtype)
+
+
+def pack_upsample(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """ConvTranspose2d weight (Cin,Cout,2,2) -> (4*Cout, Cin) with n = (dy*2+dx)*Cout + co."""
+    return w.detach().permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous().to(dtype)
+
+
+def pack_input_proj(w: Tensor) -> Tensor:
+    """Conv2d weight (E,Cin,3,3) -> (Cin*9, E) f32."""
+    return w.detach().permute(1, 2, 3, 0).reshape(-1, w.shape[0]).contiguous().float()
+
+
+def pack_output_proj(w: Tensor) -> Tensor:
+    """Conv2d weight (3,C2,3,3) -> (3, 9, C2) f32."""
+    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).contiguous().float()
+
+
+def pack_block(sd: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype: torch.dtype):
+    """Returns (BlockParams, keepalive list).  ``sd`` maps reference keys to tensors on the GPU."""
+    f = lambda k: sd[prefix + k].detach().contiguous().float()  # noqa: E731
+    t = lambda k: sd[prefix + k].detach().contiguous().to(dtype)  # noqa: E731
+    keep: Dict[str, Tensor] = {
+        "norm1_w": f("norm1.weight"), "norm1_b": f("norm1.bias"),
+        "rpb_dense": rpb_dense(sd[prefix + "attn.relative_position_bias_table"], sd[prefix + "attn.relative_position_index"]),
+        "wqkv": torch.cat([sd[prefix + "attn.qkv.to_q.weight"].detach(), sd[prefix + "attn.qkv.to_kv.weight"].detach()], 0).contiguous().to(dtype),
+        "bqkv": torch.cat([sd[prefix + "attn.qkv.to_q.bias"].detach(), sd[prefix + "attn.qkv.to_kv.bias"].detach()], 0).contiguous().float(),
+        "wproj": t("attn.proj.weight"), "bproj": f("attn.proj.bias"),
+        "norm2_w": f("norm2.weight"), "norm2_b": f("norm2.bias"),
+        "w1": t("mlp.linear1.0.weight"), "b1": f("mlp.linear1.0.bias"),
+        "wdw9": pack_dwconv(sd[prefix + "mlp.dwconv.0.weight"]), "bdw": f("mlp.dwconv.0.bias"),
+        "w2": t("mlp.linear2.0.weight"), "b2": f("mlp.linear2.0.bias"),
+    }
+    if (prefix + "modulator.weight") in sd:
+        keep["modulator"] = f("modulator.weight")
+    bp = _lib.BlockParams()
+    for name, _ in _lib.BlockParams._fields_:
+        if name in ("shift", "heads"):
+            continue
+        setattr(bp, name, keep[name].data_ptr() if name in keep else None)
+    bp.shift = int(shift)
+    bp.heads = int(heads)
+    return bp, keep
+
+
+class PackedModel:
+    """All packed weights of one ``Uformer`` + the ``uf_model_desc`` that points at them."""
+
+    def __init__(self, cfg, sd: Dict[str, Tensor], dtype: torch.dtype):
+        from .spec import STAGES
+        self.dtype = dtype
+        self.keep: List[object] = []
+        shifts = cfg.block_shifts()
+        n_blocks = sum(cfg.depths)
+        self.blocks = (_lib.BlockParams * n_blocks)()
+        i = 0
+        for s in range(9):
+            for b in range(cfg.depths[s]):
+                bp, keep = pack_block(sd, f"{STAGES[s]}.blocks.{b}.", cfg.num_heads[s], shifts[s][b], dtype)
+                self.blocks[i] = bp
+                self.keep.append(keep)
+                i += 1
+        d = _lib.ModelDesc()
+        d.embed_dim, d.dd_in, d.in_chans = cfg.embed_dim, cfg.dd_in, cfg.in_chans
+        for s in range(9):
+            d.depths[s] = cfg.depths[s]
+        d.blocks = C.cast(self.blocks, C.POINTER(_lib.BlockParams))
+        g = {
+            "in_w27": pack_input_proj(sd["input_proj.proj.0.weight"]),
+            "in_b": sd["input_proj.proj.0.bias"].detach().contiguous().float(),
+            "out_w": pack_output_proj(sd["output_proj.proj.0.weight"]),
+            "out_b": sd["output_proj.proj.0.bias"].detach().contiguous().float(),
+        }
+        for name, tns in g.items():
+            setattr(d, name, tns.data_ptr())
+        self.keep.append(g)
+        for k in range(4):
+            dw = pack_downsample(sd[f"dowsample_{k}.conv.0.weight"], dtype)
+            db = sd[f"dowsample_{k}.conv.0.bias"].detach().contiguous().float()
+            uw = pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], dtype)
+            ub = sd[f"upsample_{k}.deconv.0.bias"].detach().contiguous().float()
+            d.down_w[k], d.down_b[k], d.up_w[k], d.up_b[k] = dw.data_ptr(), db.data_ptr(), uw.data_ptr(), ub.data_ptr()
+            self.keep.append((dw, db, uw, ub))
+        self.desc = d
