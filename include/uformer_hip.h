@@ -85,6 +85,19 @@ int uf_linear_fwd(const void* A, const void* W, const float* bias, void* out, in
 int uf_qkv_fwd(const void* A, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt,
                int M, int C, int heads, uf_dtype dtype, void* stream);
 
+/* ---- a5+a6+a7 fused: LN1 -> roll -> window_partition -> +modulator -> Q/K/V projection -------
+ * (model.py:952-969 then :431-442, :497).  x f32 rows (stride ld) of the (B,H,W,C) stream; outputs as
+ * uf_qkv_fwd.  The normalised activations stay in LDS; x is read once. */
+int uf_ln_qkv_fwd(const float* x, int ld, const float* gamma, const float* beta,
+                  const float* modulator /* (64,C) or NULL */, const void* Wqkv, const float* bqkv,
+                  void* q, void* k, void* vt, int B, int H, int W, int C, int heads, int shift,
+                  uf_dtype dtype, void* stream);
+/* ---- a5+a10 fused: LN2 -> linear1 -> GELU (model.py:987, :657-658).  x f32 [M] rows (stride ld),
+ * W1 T[N][C], b1 f32[N], out T[M][N]. */
+int uf_ln_linear_gelu_fwd(const float* x, int ld, const float* gamma, const float* beta,
+                          const void* W1, const float* b1, void* out, int M, int N, int C,
+                          uf_dtype dtype, void* stream);
+
 /* ---- a8: window attention core (WindowAttention.forward model.py:494-519, without proj) ---
  * q,k,vt as produced by uf_qkv_fwd.  bias_dense f32[heads][64][64] =
  * relative_position_bias_table[relative_position_index] permuted (model.py:500-502).

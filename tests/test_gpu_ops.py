@@ -144,6 +144,44 @@ def test_linear(ops, dtype, M, N, K, act):
 
 
 @pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (64, 2), (128, 4), (256, 8), (512, 16)])
+def test_ln_fused_projections(ops, dtype, C, heads):
+    """uf_ln_qkv_fwd / uf_ln_linear_gelu_fwd == the unfused kernels' composition == the oracle's LN + linear."""
+    gen = torch.Generator().manual_seed(C + 1)
+    B, H, W = 3, 16, 24            # 1152 tokens: not a multiple of the 128-row block (tail path)
+    M = B * H * W
+    x = torch.randn(M, C, generator=gen) * 1.5 + 0.3
+    gm, bt = 1 + 0.1 * torch.randn(C, generator=gen), 0.1 * torch.randn(C, generator=gen)
+    mod = 0.5 * torch.randn(64, C, generator=gen)
+    wqkv = (torch.randn(3 * C, C, generator=gen) / C ** 0.5).to(dtype)
+    bqkv = 0.1 * torch.randn(3 * C, generator=gen)
+    w1 = (torch.randn(4 * C, C, generator=gen) / C ** 0.5).to(dtype)
+    b1 = 0.1 * torch.randn(4 * C, generator=gen)
+    hd = C // heads
+    for shift, m_ in ((0, None), (4, mod)):
+        z = O.layer_norm(x, gm, bt).reshape(B, H, W, C)
+        z = O.window_partition(torch.roll(z, shifts=(-shift, -shift), dims=(1, 2)), 8).reshape(-1, 64, C)
+        if m_ is not None:
+            z = z + m_
+        zz = z.to(dtype).float() if dtype == torch.bfloat16 else z
+        y = zz.reshape(-1, C) @ wqkv.float().t() + bqkv
+        nw = M // 64
+        qr = (y[:, :C] * hd ** -0.5).reshape(nw, 64, heads, hd).permute(0, 2, 1, 3)
+        kr = y[:, C:2 * C].reshape(nw, 64, heads, hd).permute(0, 2, 1, 3)
+        vtr = y[:, 2 * C:].reshape(nw, 64, heads, hd).permute(0, 2, 3, 1)
+        q, k, vt = ops.ln_qkv(x.cuda(), gm.cuda(), bt.cuda(), wqkv.cuda(), bqkv.cuda(), heads, B=B, H=H, W=W, shift=shift,
+                              modulator=None if m_ is None else m_.cuda())
+        check(f"ln_qkv_q_C{C}_s{shift}", q, qr, dtype)
+        check(f"ln_qkv_k_C{C}_s{shift}", k, kr, dtype)
+        check(f"ln_qkv_vt_C{C}_s{shift}", vt, vtr, dtype)
+    z = O.layer_norm(x, gm, bt)
+    zz = z.to(dtype).float() if dtype == torch.bfloat16 else z
+    ref = O.gelu_erf(zz @ w1.float().t() + b1)
+    got = ops.ln_linear_gelu(x.cuda(), gm.cuda(), bt.cuda(), w1.cuda(), b1.cuda())
+    check(f"ln_linear_gelu_C{C}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", MODES)
 def test_window_attention_golden(ops, golden, dtype):
     """WindowAttention.forward fixture from the reference (C=64, heads=2, 8 windows of a 16x16 map)."""
     from uformer_amd import packing

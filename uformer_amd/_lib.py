@@ -50,6 +50,8 @@ SIGNATURES = {
     "uf_layernorm_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, I, I, P]),
     "uf_linear_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "uf_qkv_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "uf_ln_qkv_fwd": (I, [P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "uf_ln_linear_gelu_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "uf_window_attention_fwd": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "uf_dwconv3x3_gelu_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "uf_block_workspace_bytes": (c_size_t, [I, I, I]),

@@ -196,7 +196,9 @@ extern "C" int uf_window_attention_fwd(const void* q, const void* k, const void*
     dim3 grid((n_pairs + 3) / 4), block(256);
     hipStream_t st = (hipStream_t)stream;
     const double el = (double)n_pairs * 64 * head_dim;
-    ScopedTimer tm(dtype == UF_BF16 ? "window_attn_bf16" : "window_attn_f32", 4.0 * 64 * el,
+    char tname[64] = "";
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "window_attn_%s %dx%dx%d", dtype == UF_BF16 ? "bf16" : "f32", n_windows, heads, head_dim);
+    ScopedTimer tm(tname, 4.0 * 64 * el,
                    4.0 * el * dtype_size(dtype), st);
 #define UF_ATTN_LAUNCH(TT, HDV)                                                                                  \
     hipLaunchKernelGGL((window_attn_kernel<TT, HDV>), grid, block, 0, st, (const TT*)q, (const TT*)k,            \

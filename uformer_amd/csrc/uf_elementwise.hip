@@ -48,12 +48,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int sub = threadIdx.x % LPR;
     const int m = blockIdx.x * RPB + threadIdx.x / LPR;
     const bool live = m < rows;
-    const int src = live ? (windowed ? window_row_to_token(m, H, W, shift) : m) : 0;
+    const int mc = live ? m : rows - 1;   // clamped so that the loads below are unconditional
+    const int src = windowed ? window_row_to_token(mc, H, W, shift) : mc;
     f32x4 v[V4];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
-        v[i] = live ? *reinterpret_cast<const f32x4*>(x + (size_t)src * ld_x + (i * LPR + sub) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)src * ld_x + (i * LPR + sub) * 4);
         sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
 #pragma unroll
@@ -108,40 +109,69 @@ template <> struct Vec16<float> {
     }
 };
 
+// One thread = a vertical strip of DW_R output pixels x VEC channels: each input vector is loaded
+// once per (column tap) and feeds up to 3 output rows, the 3 column-tap weights live in registers.
+constexpr int DW_R = 4;
+
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict__ x, const float* __restrict__ w9,
                                                              const float* __restrict__ bias, T* __restrict__ out, int B, int H,
                                                              int W, int C) {
     constexpr int N = Vec16<T>::N;
     const int cv = C / N;
+    const int strips = H / DW_R;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * H * W * cv) return;
+    if (idx >= (long long)B * strips * W * cv) return;
     const int c = (int)(idx % cv) * N;
-    const long long pix = idx / cv;
-    const int xw = (int)(pix % W);
-    const int yh = (int)((pix / W) % H);
-    const int b = (int)(pix / ((long long)W * H));
-    float acc[N];
+    long long rest = idx / cv;
+    const int xw = (int)(rest % W); rest /= W;
+    const int y0 = (int)(rest % strips) * DW_R;
+    const int b = (int)(rest / strips);
+    float acc[DW_R][N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = bias[c + i];
+    for (int r = 0; r < DW_R; ++r)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = yh + ky - 1;
-        if (iy < 0 || iy >= H) continue;
+        for (int i = 0; i < N; ++i) acc[r][i] = bias[c + i];
+    const T* xb = x + (size_t)b * H * W * C + c;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = xw + kx - 1;
-            if (ix < 0 || ix >= W) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+        // zero padding without guarded loads (a guarded load costs an exec-masked branch and a
+        // vmcnt(0) wait): coordinates are clamped and the column / row masks are folded into the
+        // weights / the loaded values.
+        const int ixr = xw + kx - 1;
+        const float mx = (ixr >= 0 && ixr < W) ? 1.0f : 0.0f;
+        const int ix = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
+        float wk[3][N];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int i = 0; i < N; ++i) wk[ky][i] = w9[(ky * 3 + kx) * C + c + i] * mx;
+#pragma unroll
+        for (int r = -1; r <= DW_R; ++r) {   // input row y0 + r feeds output rows r+1-ky
+            const int iyr = y0 + r;
+            const bool rowok = iyr >= 0 && iyr < H;
+            const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
             float f[N];
-            Vec16<T>::load(x + ((size_t)(b * H + iy) * W + ix) * C + c, f);
-            const float* wp = w9 + (ky * 3 + kx) * C + c;
+            Vec16<T>::load(xb + ((size_t)iy * W + ix) * C, f);
+            if (r == -1 || r == DW_R) {   // only the halo rows can fall outside the image
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc[i] = fmaf(f[i], wp[i], acc[i]);
+                for (int i = 0; i < N; ++i) f[i] = rowok ? f[i] : 0.0f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int orow = r + 1 - ky;
+                if (orow < 0 || orow >= DW_R) continue;
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[orow][i] = fmaf(f[i], wk[ky][i], acc[orow][i]);
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = gelu_erf(acc[i]);
-    Vec16<T>::store(out + (size_t)pix * C + c, acc);
+    for (int r = 0; r < DW_R; ++r) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[r][i] = gelu_erf(acc[r][i]);
+        Vec16<T>::store(out + ((size_t)(b * H + y0 + r) * W + xw) * C + c, acc[r]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -162,13 +192,15 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
         const float* plane = img + ((size_t)b * Cin + ci) * H * W;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int iy = yh + ky - 1;
-            if (iy < 0 || iy >= H) continue;
+            const int iyr = yh + ky - 1;
+            const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = xw + kx - 1;
-                if (ix < 0 || ix >= W) continue;
-                const float v = plane[(size_t)iy * W + ix];
+                const int ixr = xw + kx - 1;
+                const int ix = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
+                const bool inb = iyr >= 0 && iyr < H && ixr >= 0 && ixr < W;   // zero padding by select, loads unconditional
+                const float pv = plane[(size_t)iy * W + ix];
+                const float v = inb ? pv : 0.0f;
                 const f32x4 wv = *reinterpret_cast<const f32x4*>(w27 + (size_t)(ci * 9 + ky * 3 + kx) * E + e);
                 acc += v * wv;
             }
@@ -197,13 +229,14 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int iy = yh + ky - 1;
-        if (iy < 0 || iy >= H) continue;
+        const int iyr = yh + ky - 1;
+        const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int ix = xw + kx - 1;
-            if (ix < 0 || ix >= W) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * ld_x + sub * 4);
+            const int ixr = xw + kx - 1;
+            const int ix = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
+            const float inb = (iyr >= 0 && iyr < H && ixr >= 0 && ixr < W) ? 1.0f : 0.0f;   // zero padding, loads unconditional
+            const f32x4 v = inb * *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * ld_x + sub * 4);
             const int tap = ky * 3 + kx;
             const f32x4 w0 = *reinterpret_cast<const f32x4*>(w + (size_t)(0 * 9 + tap) * C2 + sub * 4);
             const f32x4 w1 = *reinterpret_cast<const f32x4*>(w + (size_t)(1 * 9 + tap) * C2 + sub * 4);
@@ -232,7 +265,9 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
 
 int launch_layernorm(const float* x, int ld_x, const float* gamma, const float* beta, const float* modulator, void* out,
                      int rows, int H, int W, int C, int windowed, int shift, uf_dtype dtype, hipStream_t st) {
-    ScopedTimer tm(windowed ? "layernorm_window" : "layernorm", 8.0 * rows * C, (double)rows * C * (4 + dtype_size(dtype)), st);
+    char tname[64] = "";
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "%s %dx%d", windowed ? "layernorm_window" : "layernorm", rows, C);
+    ScopedTimer tm(tname, 8.0 * rows * C, (double)rows * C * (4 + dtype_size(dtype)), st);
 #define UF_LN_CASE(CV)                                                                                                  \
     case CV: {                                                                                                          \
         constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64;                                                              \
@@ -318,16 +353,18 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
 extern "C" int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C,
                                      uf_dtype dtype, void* stream) {
     UF_REQUIRE(x && w9 && bias && out, UF_ERR_NULL, "uf_dwconv3x3_gelu_fwd: null pointer");
-    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: bad shape");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: bad shape (H must be a multiple of %d)", DW_R);
     hipStream_t st = (hipStream_t)stream;
-    ScopedTimer tm("dwconv3x3_gelu", 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), st);
+    char tname[64] = "";
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3_gelu %dx%d", B * H * W, C);
+    ScopedTimer tm(tname, 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), st);
     if (dtype == UF_BF16) {
         UF_REQUIRE(C % 8 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 8", C);
-        const long long n = (long long)B * H * W * (C / 8);
+        const long long n = (long long)B * (H / DW_R) * W * (C / 8);
         hipLaunchKernelGGL(dwconv3x3_gelu_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
     } else if (dtype == UF_F32) {
         UF_REQUIRE(C % 4 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 4", C);
-        const long long n = (long long)B * H * W * (C / 4);
+        const long long n = (long long)B * (H / DW_R) * W * (C / 4);
         hipLaunchKernelGGL(dwconv3x3_gelu_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
     } else {
         set_error("uf_dwconv3x3_gelu_fwd: dtype %d", (int)dtype);

@@ -19,72 +19,64 @@ namespace {
 constexpr int BM = 128;
 constexpr int ROWB = 128 + 16;  // bytes per LDS row: 128 B of K + 16 B pad
 
+// One 16-byte chunk of the activation tile in flight.  issue() is an UNCONDITIONAL global load from
+// a clamped address (a bounds-guarded load makes hipcc emit an exec-masked branch with a vmcnt(0)
+// wait per load, which serialises the whole staging pipeline); finish() -- called only when the
+// chunk is written to LDS, i.e. after the MFMAs of the current tile -- converts f32 sources to the
+// operand type and applies the bounds / zero-padding predicate.
 template <typename T, int AL>
-__device__ __forceinline__ u32x4 load_a_chunk(const GemmParams& p, int m, int k) {
-    constexpr int EPC = 16 / sizeof(T);
-    u32x4 z = {0, 0, 0, 0};
-    if (m >= p.M || k >= p.K) return z;
-    if constexpr (AL == A_PLAIN) {
-        return *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.A) + (size_t)m * p.lda + k);
-    } else {
-        const float* src;
-        if constexpr (AL == A_FROM_R) {
-            src = reinterpret_cast<const float*>(p.A) + (size_t)m * p.lda + k;
+struct AChunk {
+    static constexpr bool WIDE = (AL != A_PLAIN) && sizeof(T) == 2;  // 8 f32 source values -> 8 bf16
+    u32x4 lo, hi;
+    bool ok;
+    __device__ __forceinline__ void issue(const GemmParams& p, int m, int k) {
+        ok = m < p.M && k < p.K;
+        const int mc = m < p.M ? m : p.M - 1, kc = k < p.K ? k : 0;
+        const void* src;
+        if constexpr (AL == A_PLAIN) {
+            src = reinterpret_cast<const T*>(p.A) + (size_t)mc * p.lda + kc;
+        } else if constexpr (AL == A_FROM_R) {
+            src = reinterpret_cast<const float*>(p.A) + (size_t)mc * p.lda + kc;
         } else {  // A_CONV_DOWN: im2col of Conv2d(k4,s2,p1) on the token layout, k = (ky*4+kx)*C + c
-            const int tap = k / p.C, c = k - tap * p.C;
+            const int tap = kc / p.C, c = kc - tap * p.C;
             const int ky = tap >> 2, kx = tap & 3;
             const int Ho = p.H >> 1, Wo = p.W_ >> 1;
-            const int b = m / (Ho * Wo), r = m - b * (Ho * Wo);
+            const int b = mc / (Ho * Wo), r = mc - b * (Ho * Wo);
             const int oy = r / Wo, ox = r - oy * Wo;
-            const int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
-            if (iy < 0 || iy >= p.H || ix < 0 || ix >= p.W_) return z;
+            int iy = 2 * oy - 1 + ky, ix = 2 * ox - 1 + kx;
+            ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W_;     // zero padding
+            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= p.W_ ? p.W_ - 1 : ix);
             src = reinterpret_cast<const float*>(p.A) + ((size_t)(b * p.H + iy) * p.W_ + ix) * p.lda + c;
         }
-        if constexpr (EPC == 4) {
-            return *reinterpret_cast<const u32x4*>(src);
-        } else {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(src);
-            const f32x4 b2 = *reinterpret_cast<const f32x4*>(src + 4);
-            u32x4 o = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b2[0], b2[1]), pack2bf(b2[2], b2[3])};
-            return o;
-        }
+        lo = *reinterpret_cast<const u32x4*>(src);
+        if constexpr (WIDE) hi = *(reinterpret_cast<const u32x4*>(src) + 1);
     }
-}
+    __device__ __forceinline__ u32x4 finish() const {
+        u32x4 v = lo;
+        if constexpr (WIDE) {
+            v = u32x4{pack2bf(__uint_as_float(lo[0]), __uint_as_float(lo[1])), pack2bf(__uint_as_float(lo[2]), __uint_as_float(lo[3])),
+                      pack2bf(__uint_as_float(hi[0]), __uint_as_float(hi[1])), pack2bf(__uint_as_float(hi[2]), __uint_as_float(hi[3]))};
+        }
+        return ok ? v : u32x4{0, 0, 0, 0};
+    }
+};
 
 template <typename T>
-__device__ __forceinline__ u32x4 load_w_chunk(const GemmParams& p, int n, int k) {
-    u32x4 z = {0, 0, 0, 0};
-    if (n >= p.N || k >= p.K) return z;
-    return *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.W) + (size_t)n * p.K + k);
-}
+struct WChunk {
+    u32x4 v;
+    bool ok;
+    __device__ __forceinline__ void issue(const GemmParams& p, int n, int k) {
+        ok = n < p.N && k < p.K;
+        const int nc = n < p.N ? n : p.N - 1, kc = k < p.K ? k : 0;
+        v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.W) + (size_t)nc * p.K + kc);
+    }
+    __device__ __forceinline__ u32x4 finish() const { return ok ? v : u32x4{0, 0, 0, 0}; }
+};
 
 template <typename T, int EP>
 __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x4 acc) {
-    if constexpr (EP == E_STORE_T || EP == E_STORE_T_GELU) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-        f32x4 v = acc + b;
-        if constexpr (EP == E_STORE_T_GELU) {
-            v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-        }
-        store4(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n, v);
-    } else if constexpr (EP == E_QKV) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-        f32x4 v = acc + b;
-        const int C = p.heads * p.hd;
-        const int which = n / C, c = n - which * C;
-        const int h = c / p.hd, d = c - h * p.hd;
-        const int bw = m >> 6, t = m & 63;
-        const size_t base = ((size_t)bw * p.heads + h) * (size_t)(64 * p.hd);
-        if (which == 0) {
-            v *= p.qscale;  // q = q * scale (model.py:497)
-            store4(reinterpret_cast<T*>(p.q) + base + t * p.hd + d, v);
-        } else if (which == 1) {
-            store4(reinterpret_cast<T*>(p.k) + base + t * p.hd + d, v);
-        } else {
-            T* vt = reinterpret_cast<T*>(p.vt) + base + (size_t)d * 64 + t;
-            store1(vt, v[0]); store1(vt + 64, v[1]); store1(vt + 128, v[2]); store1(vt + 192, v[3]);
-        }
-    } else if constexpr (EP == E_RES_WINREV || EP == E_RES) {
+    if constexpr (EP == E_RES_WINREV || EP == E_RES) {
         int tok = m;
         if constexpr (EP == E_RES_WINREV) tok = window_row_to_token(m, p.H, p.W_, p.shift);
         const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
@@ -116,11 +108,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BUF_BYTES = (BM + BN) * ROWB;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar branches / addresses
     const int ccol = tid & 7, crow = tid >> 3;  // staging: chunk column (0..7), first row (0..31)
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  Workgroup b runs on XCD b % 8 (each XCD has a private 4 MiB L2), so the
+    // N-tiles of one M-tile are given consecutive sequence numbers ON ONE XCD: the activation tile is
+    // fetched from HBM once and re-read by its N/BN column tiles from that XCD's L2.  Placement only
+    // affects speed, never results.
+    const int n_tiles = (p.N + BN - 1) / BN;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int mt = (seq / n_tiles) * 8 + xcd;
+    if (mt * BM >= p.M) return;
+    const int m0 = mt * BM, n0 = (seq % n_tiles) * BN;
     const int wm = wave / WGN, wn = wave % WGN;
     const int fr = lane & 15, fg = lane >> 4;
+    const bool vwave = EP == E_QKV && (n0 + wn * TN * 16) >= 2 * p.heads * p.hd;  // wave-uniform
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -128,23 +130,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    u32x4 ra[A_CH], rw[W_CH];
+    AChunk<T, AL> ra[A_CH];
+    WChunk<T> rw[W_CH];
     const int nt = (p.K + BK - 1) / BK;
 
     auto g_load = [&](int t) {
         const int k = t * BK + ccol * EPC;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = load_a_chunk<T, AL>(p, m0 + crow + 32 * i, k);
+        for (int i = 0; i < A_CH; ++i) ra[i].issue(p, m0 + crow + 32 * i, k);
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) rw[i] = load_w_chunk<T>(p, n0 + crow + 32 * i, k);
+        for (int i = 0; i < W_CH; ++i) rw[i].issue(p, n0 + crow + 32 * i, k);
     };
     auto s_store = [&](int buf) {
         char* As = smem + buf * BUF_BYTES;
         char* Ws = As + BM * ROWB;
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(As + (crow + 32 * i) * ROWB + ccol * 16) = ra[i];
+        for (int i = 0; i < A_CH; ++i) *reinterpret_cast<u32x4*>(As + (crow + 32 * i) * ROWB + ccol * 16) = ra[i].finish();
 #pragma unroll
-        for (int i = 0; i < W_CH; ++i) *reinterpret_cast<u32x4*>(Ws + (crow + 32 * i) * ROWB + ccol * 16) = rw[i];
+        for (int i = 0; i < W_CH; ++i) *reinterpret_cast<u32x4*>(Ws + (crow + 32 * i) * ROWB + ccol * 16) = rw[i].finish();
     };
 
     g_load(0);
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         if (t + 1 < nt) g_load(t + 1);
+        __builtin_amdgcn_sched_barrier(0);  // keep the next tile's global loads ABOVE this tile's MFMAs
         const char* As = smem + buf * BUF_BYTES + (wm * TM * 16 + fr) * ROWB + fg * (8 * (int)sizeof(T));
         const char* Ws = smem + buf * BUF_BYTES + BM * ROWB + (wn * TN * 16 + fr) * ROWB + fg * (8 * (int)sizeof(T));
 #pragma unroll
@@ -163,22 +167,110 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             for (int j = 0; j < TM; ++j) load_frag(af[j], reinterpret_cast<const T*>(As + j * 16 * ROWB + ks * 64));
 #pragma unroll
             for (int i = 0; i < TN; ++i) load_frag(wf[i], reinterpret_cast<const T*>(Ws + i * 16 * ROWB + ks * 64));
+            // QKV: waves that own columns of the V third compute their tiles TRANSPOSED (activation as
+            // the MFMA A operand): a lane then holds 4 consecutive TOKENS of one channel, which is
+            // contiguous in the V^T layout the attention kernel reads.  Wave-uniform branch.
+            if (EP == E_QKV && vwave) {
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+                for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[i], af[j]);
+                    for (int j = 0; j < TM; ++j) mma16(acc[i][j], af[j], wf[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[i], af[j]);
+            }
         }
         if (t + 1 < nt) s_store(buf ^ 1);
         __syncthreads();
     }
 
+    constexpr bool STAGED = (EP == E_STORE_T || EP == E_STORE_T_GELU || EP == E_QKV);
+    if constexpr (STAGED) {
+        // T-typed outputs: stage the wave's tile in LDS (the main-loop buffers are free after the
+        // last barrier) and copy it out in 16-byte chunks so that every store instruction writes whole
+        // 64-256 byte runs of the destination rows instead of 8 bytes per lane.
+        constexpr int WTM = TM * 16, WTN = TN * 16;
+        constexpr int SROW = WTN * (int)sizeof(T) + 16;   // staged row stride, [m][n] orientation
+        constexpr int SROWT = WTM * (int)sizeof(T) + 16;  // transposed [n][m] orientation (V^T)
+        constexpr int STG = (WTM * SROW > WTN * SROWT) ? WTM * SROW : WTN * SROWT;
+        static_assert(4 * STG <= 2 * BUF_BYTES, "staging does not fit the main-loop LDS");
+        char* stg = smem + wave * STG;
+        const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+        const int C = p.heads * p.hd;
+        if (!vwave) {
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int n = n0 + (wn * TN + i) * 16 + fg * 4;
+            for (int i = 0; i < TN; ++i) {
+                const int n = nw0 + i * 16 + fg * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : p.N - 4));  // clamped, unconditional
+                const float sc = (EP == E_QKV && n < C) ? p.qscale : 1.0f;  // q = q * scale (model.py:497)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-            const int m = m0 + (wm * TM + j) * 16 + fr;
-            if (m < p.M && n < p.N) epilogue<T, EP>(p, m, n, acc[i][j]);
+                for (int j = 0; j < TM; ++j) {
+                    f32x4 v = acc[i][j] + b;
+                    if constexpr (EP == E_STORE_T_GELU) {
+                        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                    }
+                    if constexpr (EP == E_QKV) v *= sc;
+                    store4(reinterpret_cast<T*>(stg + (j * 16 + fr) * SROW) + i * 16 + fg * 4, v);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int n = nw0 + i * 16 + fr;
+                const float b = p.bias[n < p.N ? n : p.N - 1];
+#pragma unroll
+                for (int j = 0; j < TM; ++j) {
+                    const f32x4 v = {acc[i][j][0] + b, acc[i][j][1] + b, acc[i][j][2] + b, acc[i][j][3] + b};
+                    store4(reinterpret_cast<T*>(stg + (i * 16 + fr) * SROWT) + j * 16 + fg * 4, v);
+                }
+            }
+        }
+        __syncthreads();
+        if (!vwave) {
+            constexpr int CPR = WTN * (int)sizeof(T) / 16, RPI = 64 / CPR;
+#pragma unroll
+            for (int it = 0; it < WTM / RPI; ++it) {
+                const int r = it * RPI + lane / CPR, cb = lane % CPR;
+                const int m = mw0 + r, n = nw0 + cb * EPC;
+                if (m < p.M && n < p.N) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SROW + cb * 16);
+                    T* dst;
+                    if constexpr (EP == E_QKV) {
+                        const int which = n / C, c = n - which * C;
+                        const int h = c / p.hd, d = c - h * p.hd;
+                        dst = reinterpret_cast<T*>(which == 0 ? p.q : p.k) +
+                              (((size_t)(m >> 6) * p.heads + h) * 64 + (m & 63)) * p.hd + d;
+                    } else {
+                        dst = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n;
+                    }
+                    *reinterpret_cast<u32x4*>(dst) = val;
+                }
+            }
+        } else {
+            constexpr int CPR = WTM * (int)sizeof(T) / 16, RPI = 64 / CPR;
+#pragma unroll
+            for (int it = 0; it < WTN / RPI; ++it) {
+                const int r = it * RPI + lane / CPR, cb = lane % CPR;
+                const int n = nw0 + r, m = mw0 + cb * EPC;
+                if (m < p.M && n < p.N) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SROWT + cb * 16);
+                    const int c = n - 2 * C, h = c / p.hd, d = c - h * p.hd;
+                    T* dst = reinterpret_cast<T*>(p.vt) + (((size_t)(m >> 6) * p.heads + h) * p.hd + d) * 64 + (m & 63);
+                    *reinterpret_cast<u32x4*>(dst) = val;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int n = n0 + (wn * TN + i) * 16 + fg * 4;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int m = m0 + (wm * TM + j) * 16 + fr;
+                if (m < p.M && n < p.N) epilogue<T, EP>(p, m, n, acc[i][j]);
+            }
         }
     }
 }
@@ -197,9 +289,11 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
         }
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
-    static char name[64] = "";
-    if (!name[0]) snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d", sizeof(T) == 2 ? "bf16" : "f32", BN, AL, EP);
+    const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
+    dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
+    char name[96] = "";
+    if (timing_enabled())
+        snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d %dx%dx%d", sizeof(T) == 2 ? "bf16" : "f32", BN, AL, EP, p.M, p.N, p.K);
     const double sz = sizeof(T), mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     const double a_bytes = AL == A_PLAIN ? mk * sz : (AL == A_FROM_R ? mk * 4 : mk);  // conv-down reads each input once
     const double o_bytes = (EP == E_RES || EP == E_RES_WINREV) ? mn * 8 : ((EP == E_STORE_R || EP == E_UPSAMPLE) ? mn * 4 : mn * sz);
@@ -248,6 +342,12 @@ int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStre
                UF_ERR_ALIGN, "gemm: operands must be 16-byte aligned");
     if (aload == A_PLAIN) UF_REQUIRE(p.lda % epc == 0, UF_ERR_ALIGN, "gemm: lda=%d not a multiple of %d", p.lda, epc);
     else UF_REQUIRE(p.lda % 4 == 0, UF_ERR_ALIGN, "gemm: lda=%d not a multiple of 4", p.lda);
+    if (epi == E_STORE_T || epi == E_STORE_T_GELU || epi == E_QKV)
+        UF_REQUIRE(p.N % epc == 0, UF_ERR_SHAPE, "gemm: N=%d must be a multiple of %d for this epilogue", p.N, epc);
+    if (epi == E_QKV) {
+        const int C = p.heads * p.hd;
+        UF_REQUIRE(C == 16 || C % 32 == 0, UF_ERR_UNSUPPORTED, "qkv: C=%d must be 16 or a multiple of 32", C);
+    }
     if (aload == A_CONV_DOWN) UF_REQUIRE(p.C % 8 == 0, UF_ERR_SHAPE, "downsample: C=%d must be a multiple of 8", p.C);
     if (dtype == UF_BF16) return launch_t<bf16>(p, aload, epi, stream);
     if (dtype == UF_F32) return launch_t<float>(p, aload, epi, stream);

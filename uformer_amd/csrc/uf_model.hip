@@ -50,14 +50,13 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     const int M = B * H * W;
     const size_t sz = dtype_size(dtype);
     const int heads = p->heads, hd = C / heads;
-    // LN1 -> roll -> partition -> + modulator           (model.py:952-969)
-    int rc = launch_layernorm(x, ld, p->norm1_w, p->norm1_b, p->modulator, w.a, M, H, W, C, 1, p->shift, dtype, st);
-    if (rc) return rc;
-    // q,k,v projections                                 (model.py:431-442, :497)
+    // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
+    // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
     char* k = q + (size_t)M * C * sz;
     char* vt = k + (size_t)M * C * sz;
-    rc = uf_qkv_fwd(w.a, p->wqkv, p->bqkv, q, k, vt, M, C, heads, dtype, st);
+    int rc = uf_ln_qkv_fwd(x, ld, p->norm1_w, p->norm1_b, p->modulator, p->wqkv, p->bqkv, q, k, vt, B, H, W, C, heads,
+                           p->shift, dtype, st);
     if (rc) return rc;
     // softmax(q k^T + bias + mask) v                    (model.py:498-519)
     rc = uf_window_attention_fwd(q, k, vt, p->rpb_dense, user_mask, n_mask, w.a, M / 64, heads, hd, H, W, p->shift, dtype, st);
@@ -73,11 +72,8 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
               hipStream_t st) {
     const int M = B * H * W;
-    // LN2                                                (model.py:987)
-    int rc = launch_layernorm(x, ld, p->norm2_w, p->norm2_b, nullptr, w.a, M, H, W, C, 0, 0, dtype, st);
-    if (rc) return rc;
-    // linear1 + GELU                                     (model.py:657-658, :671)
-    rc = uf_linear_fwd(w.a, p->w1, p->b1, w.h1, M, 4 * C, C, 1, dtype, st);
+    // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671)
+    int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1, p->b1, w.h1, M, 4 * C, C, dtype, st);
     if (rc) return rc;
     // depthwise 3x3 + GELU over the whole H x W map      (model.py:659-660, :674-680)
     rc = uf_dwconv3x3_gelu_fwd(w.h1, p->wdw9, p->bdw, w.h2, B, H, W, 4 * C, dtype, st);

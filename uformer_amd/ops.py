@@ -149,6 +149,40 @@ def qkv(a: Tensor, wqkv: Tensor, bqkv: Tensor, heads: int):
     return q, k, vt
 
 
+def ln_qkv(x: Tensor, gamma: Tensor, beta: Tensor, wqkv: Tensor, bqkv: Tensor, heads: int, *, B: int, H: int, W: int,
+           shift: int = 0, modulator: Optional[Tensor] = None):
+    """Fused LN1 -> roll -> partition -> +modulator -> q,k,v^T (model.py:952-969, :431-442).  x f32 (B*H*W, C)."""
+    _dev(x, gamma, beta, wqkv, bqkv, modulator)
+    dt = uf_dtype(wqkv.dtype)
+    x = _c(x, torch.float32)
+    M, Cc = x.shape
+    hd = Cc // heads
+    q = torch.empty((M // 64, heads, 64, hd), dtype=wqkv.dtype, device=x.device)
+    k = torch.empty_like(q)
+    vt = torch.empty((M // 64, heads, hd, 64), dtype=wqkv.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_ln_qkv_fwd(_ptr(x), Cc, _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)),
+                                             _ptr(None if modulator is None else _c(modulator, torch.float32)), _ptr(_c(wqkv)),
+                                             _ptr(_c(bqkv, torch.float32)), _ptr(q), _ptr(k), _ptr(vt), B, H, W, Cc, heads, shift,
+                                             dt, _stream()), "uf_ln_qkv_fwd")
+    return q, k, vt
+
+
+def ln_linear_gelu(x: Tensor, gamma: Tensor, beta: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
+    """Fused LN2 -> linear1 -> GELU (model.py:987, :657-658).  x f32 (M, C); w1 T (N, C) -> T (M, N)."""
+    _dev(x, gamma, beta, w1, b1)
+    dt = uf_dtype(w1.dtype)
+    x = _c(x, torch.float32)
+    M, Cc = x.shape
+    N = w1.shape[0]
+    out = torch.empty((M, N), dtype=w1.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_ln_linear_gelu_fwd(_ptr(x), Cc, _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)),
+                                                     _ptr(_c(w1)), _ptr(_c(b1, torch.float32)), _ptr(out), M, N, Cc, dt, _stream()),
+                   "uf_ln_linear_gelu_fwd")
+    return out
+
+
 def window_attention_core(q: Tensor, k: Tensor, vt: Tensor, bias_dense: Tensor, *, H: int, W: int, shift: int = 0,
                           mask: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T + bias + masks) v -> (n_windows*64, C).  model.py:498-519."""
