@@ -113,6 +113,13 @@ int uf_window_attention_fwd(const void* q, const void* k, const void* vt, const 
 int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B,
                           int H, int W, int C, uf_dtype dtype, void* stream);
 
+/* ---- a10 fused: x += linear2(GELU(dwconv3x3(h1)))  (LeFF second half, model.py:674-683, :987) ----
+ * h1 T[B][H][W][4C] = GELU(linear1(LN2(x))); w9 f32[9][4C]; bdw f32[4C]; W2 T[C][4C]; b2 f32[C];
+ * x f32 rows of C (stride ld), updated in place.  The conv output never reaches HBM. */
+int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2,
+                          const float* b2, float* x, int ld, int B, int H, int W, int C,
+                          uf_dtype dtype, void* stream);
+
 /* ---- per-block parameters (packed; SURVEY.md Appendix C names in comments) ----------------- */
 typedef struct uf_block_params {
     const float* norm1_w;   /* norm1.weight (C) */

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 results database (rocprofv3 7.x writes <name>_results.db) into the per-kernel
+summary CSVs kept under profiles/: kernel-trace stats, and (if present) PMC counters per kernel."""
+import collections
+import csv
+import sqlite3
+import sys
+
+db = sqlite3.connect(sys.argv[1])
+out = sys.argv[2]
+cur = db.cursor()
+rows = cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+with open(out + "_kernel_stats.csv", "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "calls", "total_us", "avg_us", "percent"])
+    for name, calls, tot, avg, pct in rows:
+        w.writerow([name, calls, f"{tot:.3f}", f"{avg:.3f}", f"{pct:.3f}"])
+print(f"wrote {out}_kernel_stats.csv ({len(rows)} kernels)")
+n = cur.execute("select count(*) from counters_collection").fetchone()[0]
+if n:
+    disp = collections.OrderedDict()
+    for d, kn, gs, cn, val, dur in cur.execute(
+            "select dispatch_id, kernel_name, grid_size, counter_name, value, duration from counters_collection"):
+        e = disp.setdefault(d, {"k": kn, "grid": gs, "dur": dur, "c": collections.Counter()})
+        e["c"][cn] += val
+    agg = collections.OrderedDict()
+    names = set()
+    for e in disp.values():
+        a = agg.setdefault((e["k"], e["grid"]), {"n": 0, "dur": 0.0, "c": collections.Counter()})
+        a["n"] += 1
+        a["dur"] += e["dur"]
+        a["c"].update(e["c"])
+        names.update(e["c"].keys())
+    names = sorted(names)
+    with open(out + "_pmc.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_size", "dispatches", "avg_us"] + names)
+        for (k, g), a in sorted(agg.items(), key=lambda kv: -kv[1]["dur"]):
+            w.writerow([k, g, a["n"], f"{a['dur'] / a['n'] / 1e3:.2f}"] + [f"{a['c'][c] / a['n']:.0f}" for c in names])
+    print(f"wrote {out}_pmc.csv ({len(agg)} kernel/grid rows, counters: {names})")

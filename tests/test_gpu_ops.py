@@ -244,6 +244,28 @@ def test_dwconv_gelu(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("C,H,W", [(16, 8, 8), (32, 16, 24), (64, 16, 16), (128, 24, 8), (256, 16, 16), (512, 8, 16)])
+def test_dwconv_linear2_fused(ops, dtype, C, H, W):
+    """uf_dwconv_linear2_fwd == x + linear2(GELU(dwconv3x3(h1))) of the oracle (tile borders, image borders, B>1)."""
+    from uformer_amd import packing
+    gen = torch.Generator().manual_seed(C + H)
+    B = 2
+    hid = 4 * C
+    h1 = torch.randn(B, H, W, hid, generator=gen).to(dtype)
+    wd = torch.randn(hid, 1, 3, 3, generator=gen) / 3
+    bd = 0.1 * torch.randn(hid, generator=gen)
+    w2 = (torch.randn(C, hid, generator=gen) / hid ** 0.5).to(dtype)
+    b2 = 0.1 * torch.randn(C, generator=gen)
+    x = torch.randn(B * H * W, C, generator=gen)
+    h2 = O.gelu_erf(torch.nn.functional.conv2d(h1.float().permute(0, 3, 1, 2), wd, bd, padding=1, groups=hid)).permute(0, 2, 3, 1)
+    if dtype == torch.bfloat16:
+        h2 = h2.to(dtype).float()
+    ref = x + h2.reshape(-1, hid) @ w2.float().t() + b2
+    got = ops.dwconv_linear2(h1.cuda(), packing.pack_dwconv(wd).cuda(), bd.cuda(), w2.cuda(), b2.cuda(), x.cuda())
+    check(f"dwconv_linear2_C{C}_{H}x{W}", got, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", MODES)
 def test_leff_golden(golden, dtype):
     from uformer_amd import model
     g = golden("leff")

@@ -54,6 +54,7 @@ SIGNATURES = {
     "uf_ln_linear_gelu_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "uf_window_attention_fwd": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "uf_dwconv3x3_gelu_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "uf_dwconv_linear2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "uf_block_workspace_bytes": (c_size_t, [I, I, I]),
     "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
     "uf_leff_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, I, P, c_size_t, P]),

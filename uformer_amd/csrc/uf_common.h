@@ -20,16 +20,33 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 __device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+// float -> bf16 through the compiler's own conversion: on gfx950 it lowers to ONE v_cvt_pk_bf16_f32
+// per two values (round-to-nearest-even), instead of ~8 VALU ops per value of integer rounding.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, static_cast<__bf16>(f)); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const bf16x2_t v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
 
 // exact erf GELU (nn.GELU default; reference model.py:657-660)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution): ~16 VALU ops with
+// v_rcp_f32 / v_exp_f32 instead of erff's ~35 with branches.  Used wherever the result is stored as
+// bf16; the f32 (parity) mode keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_erf(x); }
+template <> __device__ __forceinline__ float gelu_t<bf16>(float x) { return gelu_fast(x); }
 
 // 8 operand elements of type T (one MFMA k-slot group per lane)
 template <typename T> struct Frag;

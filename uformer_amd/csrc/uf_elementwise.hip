@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) acc[r][i] = gelu_erf(acc[r][i]);
+        for (int i = 0; i < N; ++i) acc[r][i] = gelu_t<T>(acc[r][i]);
         Vec16<T>::store(out + ((size_t)(b * H + y0 + r) * W + xw) * C + c, acc[r]);
     }
 }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
 }
 
 template <typename T, int BN, int WGM, int WGN, int AL, int EP>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;          // elements per 128-byte K row
     constexpr int KSTEPS = BK / 32;      // MFMA k-steps (32 elements) per tile
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
                 for (int j = 0; j < TM; ++j) {
                     f32x4 v = acc[i][j] + b;
                     if constexpr (EP == E_STORE_T_GELU) {
-                        v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+                        v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]);
                     }
                     if constexpr (EP == E_QKV) v *= sc;
                     store4(reinterpret_cast<T*>(stg + (j * 16 + fr) * SROW) + i * 16 + fg * 4, v);

@@ -1,0 +1,282 @@
+// Second half of LeFF in ONE kernel (reference model.py:674-683, :987):
+//
+//     x += linear2( GELU( dwconv3x3( h1 ) ) )        h1 = GELU(linear1(LN2(x)))  [B][H][W][4C]
+//
+// The depthwise 3x3 runs over the whole H x W map (it crosses window borders), so a workgroup owns a
+// SPATIAL tile of TH x TW pixels and walks over the 4C hidden channels in chunks of 64:
+//   1. the (TH+2) x (TW+2) halo tile of the chunk is staged in LDS (zero outside the image =
+//      the convolution's zero padding); loads for chunk c+1 are issued before the stencil of chunk c;
+//   2. stencil + bias + GELU on the VALU: a thread owns 8 channels x a short column strip, taps in
+//      registers, and writes the MFMA operand tile [pixels][64] to LDS;
+//   3. MFMA: out[pixels][C] += tile x W2[:, chunk]^T, W2 fragments streamed L2 -> registers (issued
+//      before the stencil so the round trip hides under it), accumulators stay in registers.
+// The conv output (the largest tensor of the block, 4C per token) never goes to HBM.
+#include "uf_internal.h"
+
+namespace uf {
+namespace {
+
+struct Leff2Params {
+    const void* h1;                 // T [B][H][W][4C]
+    const float* w9; const float* bdw;  // f32 [9][4C], [4C]
+    const void* W2; const float* b2;    // T [C][4C], f32 [C]
+    float* x; int ld;               // residual stream rows, in place
+    int B, H, W;
+};
+
+constexpr int KC = 64;  // hidden channels per chunk
+
+template <typename T> __device__ __forceinline__ void cvt8(const char* p, float* f);
+template <> __device__ __forceinline__ void cvt8<bf16>(const char* p, float* f) {
+    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+}
+template <> __device__ __forceinline__ void cvt8<float>(const char* p, float* f) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 16);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+}
+__device__ __forceinline__ void put8(bf16* p, const float* f) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+__device__ __forceinline__ void put8(float* p, const float* f) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+}
+
+template <typename T, int C, int TH, int TW, int NT>
+__global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
+    constexpr int WAVES = NT / 64;
+    constexpr int SZ = sizeof(T);
+    constexpr int BM = TH * TW;                   // pixels per block (64 or 128)
+    constexpr int HID = 4 * C;
+    constexpr int NCH = HID / KC;                 // chunks
+    constexpr int HW_ = TW + 2, HT = (TH + 2) * HW_;  // halo tile
+    constexpr int SH = KC * SZ + 16;              // LDS row stride, halo tile [HT][KC]
+    constexpr int SAT = KC * SZ + 16;             // LDS row stride, operand tile [BM][KC]
+    constexpr int CPP = KC * SZ / 16;             // 16-byte chunks per pixel per channel chunk
+    constexpr int NLD = (HT * CPP + NT - 1) / NT;   // staged 16-byte loads per thread
+    constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;   // wave grid over (pixels, out channels)
+    constexpr int TMW = (BM / 16) / WM, TNW = (C / 16) / WN;       // 16x16 tiles per wave
+    constexpr int SR = BM * 8 / NT;               // rows of the column strip a thread convolves
+    static_assert(TMW >= 1 && TNW >= 1 && TMW * TNW <= 32, "accumulator budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Hs = smem;                              // halo tile
+    char* At = smem + HT * SH;                    // MFMA operand tile
+    float* Wl = reinterpret_cast<float*>(smem + HT * SH + BM * SAT);   // taps [9][64] + bias [64] of the chunk
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_x = p.W / TW, tiles_y = p.H / TH;
+    const int bt = blockIdx.x;
+    const int b = bt / (tiles_x * tiles_y), tr = bt - b * (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    const T* h1 = reinterpret_cast<const T*>(p.h1) + (size_t)b * p.H * p.W * HID;
+    const T* W2 = reinterpret_cast<const T*>(p.W2);
+
+    // ---- staging bookkeeping: which halo pixel / 16-byte piece each of this thread's loads covers ----
+    u32x4 stage[NLD];
+    int s_off[NLD];        // element offset of the clamped source pixel (without the chunk offset)
+    bool s_ok[NLD];        // inside the image (else zero = conv padding)
+    int s_lds[NLD];        // LDS byte offset, -1 if this thread has no load in that slot
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + NT * i;
+        const int hp = idx / CPP, piece = idx - hp * CPP;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+        s_ok[i] = idx < HT * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        s_off[i] = (cy * p.W + cx) * HID + piece * (16 / SZ);
+        s_lds[i] = idx < HT * CPP ? hp * SH + piece * 16 : -1;
+    }
+    auto halo_issue = [&](int ch) {   // unconditional loads from clamped pixels
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(h1 + s_off[i] + ch * KC);
+    };
+    // tap weights + bias of a chunk: 10 rows x 64 floats = 160 float4, one per thread (tid < 160)
+    f32x4 wstage;
+    const int wl_row = tid >> 4, wl_c4 = (tid & 15) * 4;
+    auto halo_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hs + s_lds[i]) = s_ok[i] ? stage[i] : u32x4{0, 0, 0, 0};
+        if (tid < 160) *reinterpret_cast<f32x4*>(Wl + wl_row * KC + wl_c4) = wstage;
+    };
+    auto taps_issue = [&](int ch) {   // rows 0..8 = taps, row 9 = bias (clamped row for idle threads)
+        const int row = wl_row < 10 ? wl_row : 9;
+        const float* src = row < 9 ? p.w9 + (size_t)row * HID : p.bdw;
+        wstage = *reinterpret_cast<const f32x4*>(src + ch * KC + wl_c4);
+    };
+
+    // ---- stencil role: 8 channels x SR rows of one column ----
+    const int cvec = tid & 7, sx = (tid >> 3) % TW, sy0 = ((tid >> 3) / TW) * SR;
+
+    f32x4 acc[TNW][TMW];
+#pragma unroll
+    for (int i = 0; i < TNW; ++i)
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    halo_issue(0);
+    taps_issue(0);
+    halo_store();
+    __syncthreads();
+
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+        // (a) issue everything this chunk needs from memory BEFORE the VALU-heavy stencil
+        if (ch + 1 < NCH) { halo_issue(ch + 1); taps_issue(ch + 1); }
+        Frag<T> wf[2][TNW];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TNW; ++i)
+                load_frag(wf[ks][i], W2 + (size_t)((wn * TNW + i) * 16 + fr) * HID + ch * KC + ks * 32 + fg * 8);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // (b) depthwise 3x3 + bias + GELU from the halo tile -> operand tile
+        {
+            float o[SR][8];
+#pragma unroll
+            for (int r = 0; r < SR; ++r)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[r][i] = Wl[9 * KC + cvec * 8 + i];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                float wk[3][8];   // the three taps of this column, from LDS (same address across pixels: broadcast)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) wk[ky][i] = Wl[(ky * 3 + kx) * KC + cvec * 8 + i];
+#pragma unroll
+                for (int r = -1; r <= SR; ++r) {       // halo row (sy0 + r + 1) feeds output rows r+1-ky
+                    float f[8];
+                    cvt8<T>(Hs + ((sy0 + r + 1) * HW_ + sx + kx) * SH + cvec * 8 * SZ, f);
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int orow = r + 1 - ky;
+                        if (orow < 0 || orow >= SR) continue;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) o[orow][i] = fmaf(f[i], wk[ky][i], o[orow][i]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[r][i] = gelu_t<T>(o[r][i]);
+                put8(reinterpret_cast<T*>(At + ((sy0 + r) * TW + sx) * SAT) + cvec * 8, o[r]);
+            }
+        }
+        __syncthreads();   // operand tile complete; halo tile no longer read
+
+        // (c) next chunk's halo -> LDS, then the MFMAs of this chunk
+        if (ch + 1 < NCH) halo_store();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> af[TMW];
+#pragma unroll
+            for (int j = 0; j < TMW; ++j)
+                load_frag(af[j], reinterpret_cast<const T*>(At + ((wm * TMW + j) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
+#pragma unroll
+            for (int i = 0; i < TNW; ++i)
+#pragma unroll
+                for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks][i], af[j]);
+        }
+        __syncthreads();   // halo tile of chunk ch+1 visible; operand tile free again
+    }
+
+    // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
+#pragma unroll
+    for (int i = 0; i < TNW; ++i) {
+        const int n = (wn * TNW + i) * 16 + fg * 4;
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + n);
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) {
+            const int pm = (wm * TMW + j) * 16 + fr;
+            const int ty = pm / TW, tx = pm - ty * TW;
+            float* xp = p.x + ((size_t)(b * p.H + y0 + ty) * p.W + x0 + tx) * p.ld + n;
+            *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2);
+        }
+    }
+}
+
+template <typename T, int C, int TH, int TW, int NT>
+int launch_tile(const Leff2Params& p, hipStream_t st) {
+    constexpr int SZ = sizeof(T);
+    constexpr int smem = (TH + 2) * (TW + 2) * (KC * SZ + 16) + TH * TW * (KC * SZ + 16) + 10 * KC * 4;
+    auto kern = leff2_kernel<T, C, TH, TW, NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            set_error("leff2: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
+            return UF_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    const long long M = (long long)p.B * p.H * p.W;
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_t%dx%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", TH, TW, M, C, 4 * C);
+    {
+        ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / TH) * (p.W / TW))), dim3(NT), smem, st, p);
+    }
+    return check_launch("leff2");
+}
+
+template <typename T, int C>
+int launch_c(const Leff2Params& p, hipStream_t st) {
+    // tile / block-size choice = what fits 256 unified registers per lane without spilling:
+    //   C >= 256: 8x8 pixels, 8 waves (each wave holds a quarter/eighth of the output channels)
+    //   C  = 64,128: 8x8 pixels, 4 waves;   C <= 32: 8x16 pixels when the row is wide enough
+    if constexpr (C >= 256) {
+        return launch_tile<T, C, 8, 8, 512>(p, st);
+    } else if constexpr (C >= 64) {
+        return launch_tile<T, C, 8, 8, 256>(p, st);
+    } else {
+        if (p.W % 16 == 0) return launch_tile<T, C, 8, 16, 256>(p, st);
+        return launch_tile<T, C, 8, 8, 256>(p, st);
+    }
+}
+
+template <typename T>
+int launch_t(const Leff2Params& p, int C, hipStream_t st) {
+    switch (C) {
+        case 16: return launch_c<T, 16>(p, st);
+        case 32: return launch_c<T, 32>(p, st);
+        case 64: return launch_c<T, 64>(p, st);
+        case 128: return launch_c<T, 128>(p, st);
+        case 256: return launch_c<T, 256>(p, st);
+        case 512: return launch_c<T, 512>(p, st);
+        default:
+            set_error("leff2: C=%d unsupported (16,32,64,128,256,512)", C);
+            return UF_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+}  // namespace uf
+
+using namespace uf;
+
+extern "C" int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2,
+                                     float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(h1 && w9 && bdw && W2 && b2 && x, UF_ERR_NULL, "uf_dwconv_linear2_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: B=%d H=%d W=%d (multiples of 8)", B, H, W);
+    UF_REQUIRE(ld >= C && ld % 4 == 0, UF_ERR_ALIGN, "uf_dwconv_linear2_fwd: ld=%d", ld);
+    UF_REQUIRE(((uintptr_t)h1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w9 % 16) == 0 &&
+                   ((uintptr_t)bdw % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
+               UF_ERR_ALIGN, "uf_dwconv_linear2_fwd: operands must be 16-byte aligned");
+    UF_REQUIRE((long long)B * H * W * 4LL * C < 0x7fffffffLL, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: tensor too large for 32-bit indexing");
+    Leff2Params p{};
+    p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
+    if (dtype == UF_F32) return launch_t<float>(p, C, st);
+    set_error("uf_dwconv_linear2_fwd: dtype %d", (int)dtype);
+    return UF_ERR_UNSUPPORTED;
+}

@@ -11,6 +11,8 @@
 // weight row is read by exactly one wave of the block), reads activation fragments from LDS and
 // issues 16 MFMAs per k-step.  The epilogue stages 16 rows at a time in a private LDS slab and
 // writes whole 128/256-byte row segments (q, k, v^T in the attention layout, or the LeFF hidden).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "uf_internal.h"
@@ -26,27 +28,13 @@ struct LnGemmParams {
     int H, W, windowed, shift;
     void* out; int ldo;              // EP_GELU: T[M][ldo]
     void* q; void* k; void* vt; int heads, hd; float qscale;  // EP_QKV
+    int dbg;                         // UF_LNGEMM_DBG ablation bits (1: no LN loads, 2: no MFMA loop, 4: no stores)
 };
 
 enum { EP_QKV = 0, EP_GELU = 1 };
 
-// Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7): the bf16 path's GELU; the f32 path keeps erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
-template <typename T> __device__ __forceinline__ float gelu_t(float x);
-template <> __device__ __forceinline__ float gelu_t<bf16>(float x) { return gelu_fast(x); }
-template <> __device__ __forceinline__ float gelu_t<float>(float x) { return gelu_erf(x); }
-
 template <typename T, int C, int BM, int EP>
-__global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
+__global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
     constexpr int SZ = sizeof(T);
     constexpr int EPC = 16 / SZ;
     constexpr int SA = C * SZ + 16;               // LDS row stride of the operand tile
@@ -72,7 +60,7 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
         static_assert(NP % U == 0, "pass batching");
         const int sub = tid % LPR;
 #pragma unroll 1
-        for (int r0 = 0; r0 < BM; r0 += RPP * U) {
+        for (int r0 = (p.dbg & 1) ? BM : 0; r0 < BM; r0 += RPP * U) {
             f32x4 v[U][V4];
             bool live[U];
 #pragma unroll
@@ -123,6 +111,31 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
     const int n_units = MH * (g1 - g0);
     const T* Wt = reinterpret_cast<const T*>(p.Wt);
     const int Cq = p.heads * p.hd;  // == C for the QKV projection
+    // Weight loads are UNCONDITIONAL (hipcc wraps a guarded load in an exec-masked branch with a
+    // vmcnt(0) wait, which would serialise the prefetch ring): rows past N are clamped to a valid
+    // row -- their products land in accumulator columns that are never stored -- and for C = 16 the
+    // k-slots 16..31 read slot 0 again and are multiplied by the zeroed activation fragment.
+    const T* wrow[4];
+    Frag<T> wf[RING][4];
+    auto wload = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 32);
+    };
+    // first RING-1 k-steps of a unit's weights; issued for unit u+4 BEFORE the epilogue of unit u so
+    // the L2 round trip hides under the epilogue instead of stalling the next unit's first MFMAs.
+    auto unit_prefetch = [&](int u) {
+        const int nb = (g0 + u / MH) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int n = nb + i * 16 + fr;
+            n = n < p.N ? n : p.N - 1;
+            wrow[i] = Wt + (size_t)n * C + (fg * 8 < C ? fg * 8 : 0);
+        }
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s)
+            if (s < KS) wload(s, s);
+    };
+    if (wave < n_units) unit_prefetch(wave);
 #pragma unroll 1
     for (int u = wave; u < n_units; u += 4) {
         const int mh = u % MH, ng = g0 + u / MH;
@@ -137,22 +150,6 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        // Weight loads are UNCONDITIONAL (hipcc wraps a guarded load in an exec-masked branch with a
-        // vmcnt(0) wait, which would serialise the prefetch ring): rows past N are clamped to a valid
-        // row -- their products land in accumulator columns that are never stored -- and for C = 16 the
-        // k-slots 16..31 read slot 0 again and are multiplied by the zeroed activation fragment.
-        const T* wrow[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int n = nbase + i * 16 + fr;
-            n = n < p.N ? n : p.N - 1;
-            wrow[i] = Wt + (size_t)n * C + (fg * 8 < C ? fg * 8 : 0);
-        }
-        Frag<T> wf[RING][4];
-        auto wload = [&](int ks, int slot) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 32);
-        };
         // Software pipeline, pinned with sched_barrier (left alone, hipcc sinks the prefetch loads next
         // to their uses -> vmcnt(1) before every MFMA group -> one L2 round trip per k-step):
         //   weights for k-step ks+2 and activation fragments for ks+1 are issued BEFORE the 16 MFMAs of ks.
@@ -165,9 +162,6 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
                 else af[slot][j].zero();
             }
         };
-#pragma unroll
-        for (int s = 0; s < RING - 1; ++s)
-            if (s < KS) wload(s, s);
         aload(0, 0);
         auto kloop = [&](auto mode_tag) {
             constexpr int MODE = decltype(mode_tag)::value;   // 0: plain tiles, 1: all V tiles, 2: mixed unit
@@ -191,9 +185,26 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (EP != EP_QKV || nv == 4) kloop(std::integral_constant<int, 0>{});
+        if (p.dbg & 2) {
+        } else if (EP != EP_QKV || nv == 4) kloop(std::integral_constant<int, 0>{});
         else if (nv == 0) kloop(std::integral_constant<int, 1>{});
         else kloop(std::integral_constant<int, 2>{});
+        if (u + 4 < n_units) unit_prefetch(u + 4);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // per-tile destination info for the q/k/v^T layouts, once per unit (scalar): tile i covers
+        // channels [nbase+16i, +16) = 16 consecutive d of ONE head of q, k or v.
+        int t_h[4], t_d[4], t_w[4];
+        if constexpr (EP == EP_QKV) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int nt_ = nbase + i * 16;
+                t_w[i] = nt_ / Cq;
+                const int c_ = nt_ - t_w[i] * Cq;
+                t_h[i] = c_ / p.hd;
+                t_d[i] = c_ - t_h[i] * p.hd;
+            }
+        }
 
         // ---- epilogue A: [token][channel] tiles (q, k, LeFF hidden): one 16-row m-tile per pass ----
         if (nv > 0) {
@@ -225,13 +236,15 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
                     const int idx = it * 64 + lane;
                     const int r = idx / CPR, cb = idx % CPR;
                     const int m = m0 + mbase + j * 16 + r, n = nbase + cb * EPC;
-                    if (m < p.M && n < p.N && (cb * EPC) / 16 < nv) {
+                    if (m < p.M && n < p.N && (cb * EPC) / 16 < nv && !(p.dbg & 4)) {
                         const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SS + cb * 16);
                         T* dst;
                         if constexpr (EP == EP_QKV) {
-                            const int which = n / Cq, c = n - which * Cq;
-                            const int h = c / p.hd, d = c - h * p.hd;
-                            dst = reinterpret_cast<T*>(which == 0 ? p.q : p.k) + (((size_t)(m >> 6) * p.heads + h) * 64 + (m & 63)) * p.hd + d;
+                            const int ti = (cb * EPC) >> 4;   // 16-column tile of this chunk (lane-constant per pass)
+                            const int h = ti == 0 ? t_h[0] : (ti == 1 ? t_h[1] : (ti == 2 ? t_h[2] : t_h[3]));
+                            const int d = (ti == 0 ? t_d[0] : (ti == 1 ? t_d[1] : (ti == 2 ? t_d[2] : t_d[3]))) + ((cb * EPC) & 15);
+                            const int w = ti == 0 ? t_w[0] : (ti == 1 ? t_w[1] : (ti == 2 ? t_w[2] : t_w[3]));
+                            dst = reinterpret_cast<T*>(w == 0 ? p.q : p.k) + (((size_t)(m >> 6) * p.heads + h) * 64 + (m & 63)) * p.hd + d;
                         } else {
                             dst = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n;
                         }
@@ -261,9 +274,9 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
                         const int idx = it * 64 + lane;
                         const int r = idx / CPR, cb = idx % CPR;
                         const int n = nbase + i * 16 + r, m = m0 + mbase + cb * EPC;
-                        if (m < p.M && n < p.N) {
+                        if (m < p.M && n < p.N && !(p.dbg & 4)) {
                             const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SS + cb * 16);
-                            const int c = n - 2 * Cq, h = c / p.hd, d = c - h * p.hd;
+                            const int h = t_h[i], d = t_d[i] + r;   // tile i of the unit, channel row r
                             T* dst = reinterpret_cast<T*>(p.vt) + (((size_t)(m >> 6) * p.heads + h) * p.hd + d) * 64 + (m & 63);
                             *reinterpret_cast<u32x4*>(dst) = val;
                         }
@@ -276,11 +289,14 @@ __global__ __launch_bounds__(256) void ln_gemm_kernel(const LnGemmParams p) {
 }
 
 template <typename T, int C, int BM, int EP>
-int launch_one(const LnGemmParams& p, hipStream_t st) {
+int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     constexpr int SZ = sizeof(T);
     constexpr int smem = BM * (C * SZ + 16) + 4 * 16 * (64 * SZ + 16);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = ln_gemm_kernel<T, C, BM, EP>;
+    static const int dbg_env = getenv("UF_LNGEMM_DBG") ? atoi(getenv("UF_LNGEMM_DBG")) : 0;
+    LnGemmParams p = p_in;
+    p.dbg = dbg_env;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -309,8 +325,9 @@ int launch_bm(const LnGemmParams& p, hipStream_t st) {
     // 128-row blocks when the operand tile fits 64 KiB of LDS and there are enough blocks to fill
     // 256 CUs twice over; otherwise 64-row blocks.
     constexpr bool fits128 = 128 * (C * (int)sizeof(T) + 16) <= 68 * 1024;
+    static const int bm_env = getenv("UF_LNGEMM_BM") ? atoi(getenv("UF_LNGEMM_BM")) : 0;   // tuning override
     if constexpr (fits128) {
-        if (p.M >= 128 * 512) return launch_one<T, C, 128, EP>(p, st);
+        if ((p.M >= 128 * 512 && bm_env != 64) || bm_env == 128) return launch_one<T, C, 128, EP>(p, st);
     }
     return launch_one<T, C, 64, EP>(p, st);
 }

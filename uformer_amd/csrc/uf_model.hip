@@ -75,14 +75,9 @@ int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671)
     int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1, p->b1, w.h1, M, 4 * C, C, dtype, st);
     if (rc) return rc;
-    // depthwise 3x3 + GELU over the whole H x W map      (model.py:659-660, :674-680)
-    rc = uf_dwconv3x3_gelu_fwd(w.h1, p->wdw9, p->bdw, w.h2, B, H, W, 4 * C, dtype, st);
-    if (rc) return rc;
-    // linear2 + residual                                 (model.py:661, :682, :987)
-    GemmParams g{};
-    g.A = w.h2; g.lda = 4 * C; g.W = p->w2; g.bias = p->b2; g.M = M; g.N = C; g.K = 4 * C;
-    g.out = x; g.ldo = ld; g.resid = x; g.ldr = ld;
-    return launch_gemm(g, A_PLAIN, E_RES, dtype, st);
+    // depthwise 3x3 + GELU over the whole H x W map, linear2, + residual: one kernel, the conv output
+    // stays on chip                                      (model.py:659-661, :674-682, :987)
+    return uf_dwconv_linear2_fwd(w.h1, p->wdw9, p->bdw, p->w2, p->b2, x, ld, B, H, W, C, dtype, st);
 }
 
 }  // namespace

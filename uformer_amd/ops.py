@@ -212,6 +212,21 @@ def dwconv3x3_gelu(x: Tensor, w9: Tensor, bias: Tensor) -> Tensor:
     return out
 
 
+def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
+    """x + linear2(GELU(dwconv3x3(h1))) (model.py:674-683, :987).  h1 T(B,H,W,4C); x f32 (B*H*W, C); returns new x."""
+    _dev(h1, w9, bdw, w2, b2, x)
+    dt = uf_dtype(h1.dtype)
+    h1 = _c(h1)
+    B, H, W, hid = h1.shape
+    out = _c(x, torch.float32).clone()
+    Cc = out.shape[-1]
+    with torch.cuda.device(h1.device):
+        _lib.check(_lib.load().uf_dwconv_linear2_fwd(_ptr(h1), _ptr(_c(w9, torch.float32)), _ptr(_c(bdw, torch.float32)),
+                                                     _ptr(_c(w2, h1.dtype)), _ptr(_c(b2, torch.float32)), _ptr(out), Cc, B, H, W, Cc,
+                                                     dt, _stream()), "uf_dwconv_linear2_fwd")
+    return out
+
+
 def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int) -> Tensor:
     """x f32 (B*H*W, C) -> f32 (B*H/2*W/2, 2C).  Downsample.forward model.py:739-746."""
     _dev(x, w_packed, bias)
