@@ -38,7 +38,7 @@ __device__ __forceinline__ void load_vt(Frag<float>& f, const float* p0, const f
 }
 
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void window_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+__global__ __launch_bounds__(256, 4) void window_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                           const T* __restrict__ vt,
                                                           const float* __restrict__ bias_dense,
                                                           const float* __restrict__ mask, int n_mask, T* __restrict__ out,

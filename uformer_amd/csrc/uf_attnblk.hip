@@ -1,0 +1,370 @@
+// The whole attention half of a LeWin block in ONE kernel, one workgroup per 8x8 window
+// (reference model.py:951-986):
+//
+//   x[win] += proj( softmax( (LN1(x)[win] + modulator) Wq^T * scale . ((..) Wk^T)^T + bias + mask ) (..) Wv^T )
+//
+// Phase 0  LN1 + roll/partition gather (+ modulator) -> Xn [64][C] in LDS (x read once).
+// Phase 1  per (head, query-tile group) unit, one wave: q/k/v = Xn W^T on the MFMA with weight
+//          fragments streamed L2 -> registers.  Q and K tiles are computed with the weight as the
+//          MFMA A operand, V with the activation as A operand; with those two orientations the
+//          ACCUMULATOR registers of q, k and v are already laid out exactly as the operand
+//          fragments of S^T = K Q^T and O^T = V^T P^T (a lane holds 8 k-slots of one row; only the
+//          pairing of slots between the two operands matters).  So q, k, v, the 64x64 scores and P
+//          never leave registers: no LDS, no HBM.  Softmax: 16 in-lane values + 2 xor steps.
+//          The head's output goes to the O tile [64][C] in LDS.
+// Phase 2  proj: out = O Wp^T (+bias), window_reverse + roll back folded into the store index,
+//          + residual, in place on the f32 stream.
+// HBM traffic of the attention half: x once in, x once out, weights from L2.
+#include <type_traits>
+
+#include "uf_internal.h"
+
+namespace uf {
+namespace {
+
+struct AttnBlkParams {
+    float* x; int ld;
+    const float* gamma; const float* beta; const float* modulator;
+    const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
+    const float* bias_dense;               // f32[heads][64][64]
+    const float* mask; int n_mask;         // optional dense mask (n_mask,64,64)
+    const void* Wp; const float* bp;       // T[C][C], f32[C]
+    int n_windows, H, W, shift;
+    float qscale;
+};
+
+template <typename T> struct FragFromAcc;
+template <> struct FragFromAcc<bf16> {
+    static __device__ __forceinline__ void make(Frag<bf16>& f, f32x4 a, f32x4 b) {
+        f.v = u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    }
+};
+template <> struct FragFromAcc<float> {
+    static __device__ __forceinline__ void make(Frag<float>& f, f32x4 a, f32x4 b) { f.lo = a; f.hi = b; }
+};
+
+template <typename T, int C, int NT>
+__global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p) {
+    constexpr int SZ = sizeof(T);
+    constexpr int WAVES = NT / 64;
+    constexpr int HEADS = C / 32;
+    constexpr int SA = C * SZ + 16;                 // LDS row stride of Xn and O
+    constexpr int KS = C / 32;                      // k-steps of the projections
+    // unit = (head, group of QT query tiles); heads >= 4: one unit per head
+    constexpr int QT = HEADS >= 4 ? 4 : HEADS;      // query tiles per unit (4, 2 or 1)
+    constexpr int UNITS = HEADS * (4 / QT);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Xn = smem;
+    char* Os = smem + 64 * SA;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int bw = blockIdx.x;                      // window index (image-major, as window_partition)
+    const int m0 = bw * 64;
+
+    // ---------------- phase 0: LN1 (+gather, +modulator) -> Xn --------------------------------------
+    {
+        constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
+        constexpr int V4 = C / (4 * LPR);
+        constexpr int RPP = NT / LPR;
+        constexpr int NP = 64 / RPP;
+        constexpr int U = (8 / V4) < NP ? (8 / V4) : NP;
+        static_assert(NP >= 1 && NP % U == 0, "pass batching");
+        const int sub = tid % LPR;
+#pragma unroll 1
+        for (int r0 = 0; r0 < 64; r0 += RPP * U) {
+            f32x4 v[U][V4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int src = window_row_to_token(m0 + r0 + u * RPP + tid / LPR, p.H, p.W, p.shift);
+#pragma unroll
+                for (int i = 0; i < V4; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = r0 + u * RPP + tid / LPR;
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
+#pragma unroll
+                for (int o = LPR >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                const float mean = sum * (1.0f / C);
+                float sq = 0.f;
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    v[u][i] -= mean;
+                    sq += (v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1]) + (v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3]);
+                }
+#pragma unroll
+                for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+                const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+#pragma unroll
+                for (int i = 0; i < V4; ++i) {
+                    const int c = (i * LPR + sub) * 4;
+                    f32x4 y = v[u][i] * rstd * *reinterpret_cast<const f32x4*>(p.gamma + c) + *reinterpret_cast<const f32x4*>(p.beta + c);
+                    if (p.modulator) y += *reinterpret_cast<const f32x4*>(p.modulator + (size_t)row * C + c);  // model.py:966-969
+                    store4(reinterpret_cast<T*>(Xn + row * SA) + c, y);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // SW-MSA mask predicate of this window (model.py:924-942), evaluated in registers
+    const int nWc = p.W >> 3, nW = (p.H >> 3) * nWc;
+    const int wi = bw % nW;
+    const bool last_r = p.shift > 0 && (wi / nWc) == (p.H >> 3) - 1;
+    const bool last_c = p.shift > 0 && (wi % nWc) == nWc - 1;
+    const float* mk = p.mask ? p.mask + (size_t)(bw % p.n_mask) * 4096 : nullptr;
+    const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
+
+    // ---------------- phase 1: per-unit QKV projection + attention, all in registers -------------------
+#pragma unroll 1
+    for (int u = wave; u < UNITS; u += WAVES) {
+        const int h = u / (4 / QT), q0 = (u % (4 / QT)) * QT;   // head, first query tile
+        f32x4 aq[2][QT], ak[2][4], av[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < QT; ++j) aq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ak[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        }
+        // weight rows of this head: q rows h*32+16i+fr, k rows C+.., v rows 2C+..; k offset fg*8
+        const T* wrow[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + (size_t)((i >> 1) * C + h * 32 + (i & 1) * 16 + fr) * C + fg * 8;
+        Frag<T> wf[2][6], af[2][4];
+        Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
+        auto wload = [&](int ks, int slot) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 32);
+        };
+        auto aload = [&](int ks, int slot) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+            if constexpr (QT < 4) {
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+                    load_frag(afq[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+            }
+        };
+        wload(0, 0);
+        aload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) { wload(ks + 1, (ks + 1) & 1); aload(ks + 1, (ks + 1) & 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            const int s = ks & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < QT; ++j) {                                                 // q: weight as A operand
+                    if constexpr (QT < 4) mma16(aq[i][j], wf[s][i], afq[s][j]);
+                    else mma16(aq[i][j], wf[s][i], af[s][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(ak[i][j], wf[s][2 + i], af[s][j]);         // k: weight as A operand
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(av[i][j], af[s][j], wf[s][4 + i]);         // v: activation as A operand
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // bias (+ scale on q, model.py:497), then the accumulators ARE the attention operands
+        Frag<T> qf[QT], kf[4], vtf[2][2];
+        {
+            const f32x4 bq0 = *reinterpret_cast<const f32x4*>(p.bqkv + h * 32 + fg * 4), bq1 = *reinterpret_cast<const f32x4*>(p.bqkv + h * 32 + 16 + fg * 4);
+            const f32x4 bk0 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + 16 + fg * 4);
+            const float bv0 = p.bqkv[2 * C + h * 32 + fr], bv1 = p.bqkv[2 * C + h * 32 + 16 + fr];
+#pragma unroll
+            for (int j = 0; j < QT; ++j) FragFromAcc<T>::make(qf[j], (aq[0][j] + bq0) * p.qscale, (aq[1][j] + bq1) * p.qscale);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) FragFromAcc<T>::make(kf[j], ak[0][j] + bk0, ak[1][j] + bk1);
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                FragFromAcc<T>::make(vtf[0][sk], av[0][2 * sk] + bv0, av[0][2 * sk + 1] + bv0);
+                FragFromAcc<T>::make(vtf[1][sk], av[1][2 * sk] + bv1, av[1][2 * sk + 1] + bv1);
+            }
+        }
+        // S^T = K Q^T : s[kt][j] -> lane: query (q0+j)*16+fr, keys 16kt+4fg+r
+        f32x4 s[4][QT];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                s[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                mma16(s[kt][j], kf[kt], qf[j]);
+            }
+        const float* bh = p.bias_dense + (size_t)h * 4096;
+        float inv[QT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            const int qi = (q0 + j) * 16 + fr;
+            const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                const int k0 = kt * 16 + fg * 4;
+                f32x4 v = s[kt][j] + *reinterpret_cast<const f32x4*>(bh + qi * 64 + k0);
+                if (mk) v += *reinterpret_cast<const f32x4*>(mk + qi * 64 + k0);
+                const bool dy = last_r && (((k0 >> 3) >= 4) != q_lo_y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool k_lo_x = ((k0 & 7) + r) >= 4;
+                    if (dy || (last_c && (k_lo_x != q_lo_x))) v[r] += -100.0f;
+                    mx = fmaxf(mx, v[r]);
+                }
+                s[kt][j] = v;
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __expf(s[kt][j][r] - mx);
+                    s[kt][j][r] = e;
+                    sum += e;
+                }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            inv[j] = 1.0f / sum;
+        }
+        // O^T = V^T P^T ; o[dt][j]: lane query fr, d = 16dt+4fg+r
+        f32x4 o[2][QT];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) o[dt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sk = 0; sk < 2; ++sk)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                Frag<T> pf;
+                FragFromAcc<T>::make(pf, s[2 * sk][j], s[2 * sk + 1][j]);
+                mma16(o[0][j], vtf[0][sk], pf);
+                mma16(o[1][j], vtf[1][sk], pf);
+            }
+        // head merge (model.py:519): O[token][h*32 + d]
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            T* orow = reinterpret_cast<T*>(Os + ((q0 + j) * 16 + fr) * SA) + h * 32 + fg * 4;
+            store4(orow, o[0][j] * inv[j]);
+            store4(orow + 16, o[1][j] * inv[j]);
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------
+    {
+        constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;
+        constexpr int TNW = (C / 16) / WN, TMW = (4 / WM) > 0 ? (4 / WM) : 1;
+        static_assert(WM <= 4, "more waves than 16-row tiles");
+        const int wm = wave / WN, wn = wave % WN;
+        const T* Wp = reinterpret_cast<const T*>(p.Wp);
+        f32x4 acc[TNW][TMW];
+#pragma unroll
+        for (int i = 0; i < TNW; ++i)
+#pragma unroll
+            for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Frag<T> wf[2][TNW], af[2][TMW];
+        auto wload = [&](int ks, int slot) {
+#pragma unroll
+            for (int i = 0; i < TNW; ++i) load_frag(wf[slot][i], Wp + (size_t)((wn * TNW + i) * 16 + fr) * C + ks * 32 + fg * 8);
+        };
+        auto aload = [&](int ks, int slot) {
+#pragma unroll
+            for (int j = 0; j < TMW; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Os + ((wm * TMW + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+        };
+        wload(0, 0);
+        aload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) { wload(ks + 1, (ks + 1) & 1); aload(ks + 1, (ks + 1) & 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TNW; ++i)
+#pragma unroll
+                for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks & 1][i], af[ks & 1][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) {
+            const int tok = window_row_to_token(m0 + (wm * TMW + j) * 16 + fr, p.H, p.W, p.shift);
+            float* xr = p.x + (size_t)tok * p.ld;
+#pragma unroll
+            for (int i = 0; i < TNW; ++i) {
+                const int n = (wn * TNW + i) * 16 + fg * 4;
+                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bp + n);
+                *reinterpret_cast<f32x4*>(xr + n) = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);
+            }
+        }
+    }
+}
+
+template <typename T, int C, int NT>
+int launch_one(const AttnBlkParams& p, hipStream_t st) {
+    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = attn_block_kernel<T, C, NT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) {
+            set_error("attn_block: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
+            return UF_ERR_LAUNCH;
+        }
+        attr_done = true;
+    }
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "attn_block_%s %dx%d", sizeof(T) == 2 ? "bf16" : "f32", p.n_windows * 64, C);
+    const double M = (double)p.n_windows * 64;
+    {
+        ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0), M * C * 8.0 + 4.0 * C * C * sizeof(T), st);
+        hipLaunchKernelGGL(kern, dim3(p.n_windows), dim3(NT), smem, st, p);
+    }
+    return check_launch("attn_block");
+}
+
+}  // namespace
+
+// true when the fused kernel covers (dtype, C, head_dim); otherwise the caller uses the 3-kernel path
+bool attn_block_supported(uf_dtype dtype, int C, int heads) {
+    if (heads <= 0 || C != heads * 32) return false;
+    if (dtype == UF_BF16) return C == 32 || C == 64 || C == 128 || C == 256 || C == 512;
+    return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
+}
+
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, const float* mask, int n_mask,
+                      uf_dtype dtype, hipStream_t st) {
+    AttnBlkParams p{};
+    p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
+    p.Wqkv = bp->wqkv; p.bqkv = bp->bqkv; p.bias_dense = bp->rpb_dense; p.mask = mask; p.n_mask = n_mask;
+    p.Wp = bp->wproj; p.bp = bp->bproj;
+    p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
+    p.qscale = (float)(1.0 / sqrt(32.0));
+#define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
+    if (dtype == UF_BF16) {
+        switch (C) {
+            case 32: UF_AB(bf16, 32, 256);
+            case 64: UF_AB(bf16, 64, 256);
+            case 128: UF_AB(bf16, 128, 256);
+            case 256: UF_AB(bf16, 256, 256);
+            case 512: UF_AB(bf16, 512, 512);
+        }
+    } else {
+        switch (C) {
+            case 32: UF_AB(float, 32, 256);
+            case 64: UF_AB(float, 64, 256);
+            case 128: UF_AB(float, 128, 256);
+            case 256: UF_AB(float, 256, 256);
+        }
+    }
+#undef UF_AB
+    set_error("attn_block: unsupported C=%d for dtype %d", C, (int)dtype);
+    return UF_ERR_UNSUPPORTED;
+}
+
+}  // namespace uf

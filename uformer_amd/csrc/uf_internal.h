@@ -31,4 +31,9 @@ struct GemmParams {
 // dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream);
 
+// fused attention half (uf_attnblk.hip)
+bool attn_block_supported(uf_dtype dtype, int C, int heads);
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, const float* mask, int n_mask,
+                      uf_dtype dtype, hipStream_t st);
+
 }  // namespace uf

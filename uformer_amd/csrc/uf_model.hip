@@ -2,6 +2,8 @@
 // Uformer forward, expressed as launches of the kernels in uf_gemm / uf_attn / uf_elementwise.
 // Mirrors LeWinTransformerBlock.forward (model.py:908-989), BasicUformerLayer.forward
 // (:1054-1060) and Uformer.forward (:1269-1305) of the reference.
+#include <stdlib.h>
+
 #include "uf_internal.h"
 
 namespace uf {
@@ -50,6 +52,10 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     const int M = B * H * W;
     const size_t sz = dtype_size(dtype);
     const int heads = p->heads, hd = C / heads;
+    // one fused kernel per window when the shape is covered (head_dim 32): LN1, q/k/v, attention, proj,
+    // window_reverse and the residual never leave the CU                       (model.py:951-986)
+    static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
+    if (!no_fuse && attn_block_supported(dtype, C, heads)) return launch_attn_block(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, st);
     // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
     // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
