@@ -52,6 +52,18 @@ int uf_last_error(char* buf, size_t n);
  * returns the length the full text needs.  bench.py uses it for the live roofline figure. */
 int uf_timing_enable(int on);
 int uf_timing_report(char* json, size_t n);
+/* development aid: device buffer (u64) that instrumented kernels fill with cycle-counter stamps; NULL = off */
+int uf_debug_set_tbuf(void* p);
+
+/* ---- fragment-major weights ------------------------------------------------------------------
+ * The fused kernels stream nn.Linear weights W[N][K] straight from L2 into MFMA operand registers.
+ * They take W re-laid out so that one wave-level load is 1 KiB contiguous:
+ *     out[((n/16 * KS + k/32) * 64 + ((k%32)/8)*16 + n%16) * 8 + k%8] = W[n][k],   KS = ceil(K/32),
+ * zero padded in k.  Arguments named *_fm below are in this layout (uf_weight_fm_elems elements).
+ * The relative-position bias has the analogous layout rpb_fm[h][qt][kt][lane][4] =
+ * bias[h][16qt + lane%16][16kt + 4(lane/16) + 0..3]. */
+size_t uf_weight_fm_elems(int N, int K);
+int uf_pack_weight_fm(const void* w_rowmajor, void* out_fm, int N, int K, uf_dtype dtype, void* stream);
 
 /* ---- a1-a4: index-only ops (bit exact) -------------------------------------------------- */
 /* torch.roll(x,(-shift,-shift)) + window_partition: model.py:957, :704-715.
@@ -89,13 +101,13 @@ int uf_qkv_fwd(const void* A, const void* Wqkv, const float* bqkv, void* q, void
  * (model.py:952-969 then :431-442, :497).  x f32 rows (stride ld) of the (B,H,W,C) stream; outputs as
  * uf_qkv_fwd.  The normalised activations stay in LDS; x is read once. */
 int uf_ln_qkv_fwd(const float* x, int ld, const float* gamma, const float* beta,
-                  const float* modulator /* (64,C) or NULL */, const void* Wqkv, const float* bqkv,
+                  const float* modulator /* (64,C) or NULL */, const void* Wqkv_fm, const float* bqkv,
                   void* q, void* k, void* vt, int B, int H, int W, int C, int heads, int shift,
                   uf_dtype dtype, void* stream);
 /* ---- a5+a10 fused: LN2 -> linear1 -> GELU (model.py:987, :657-658).  x f32 [M] rows (stride ld),
- * W1 T[N][C], b1 f32[N], out T[M][N]. */
+ * W1_fm = fragment-major T[N][C], b1 f32[N], out T[M][N]. */
 int uf_ln_linear_gelu_fwd(const float* x, int ld, const float* gamma, const float* beta,
-                          const void* W1, const float* b1, void* out, int M, int N, int C,
+                          const void* W1_fm, const float* b1, void* out, int M, int N, int C,
                           uf_dtype dtype, void* stream);
 
 /* ---- a8: window attention core (WindowAttention.forward model.py:494-519, without proj) ---
@@ -114,9 +126,9 @@ int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, voi
                           int H, int W, int C, uf_dtype dtype, void* stream);
 
 /* ---- a10 fused: x += linear2(GELU(dwconv3x3(h1)))  (LeFF second half, model.py:674-683, :987) ----
- * h1 T[B][H][W][4C] = GELU(linear1(LN2(x))); w9 f32[9][4C]; bdw f32[4C]; W2 T[C][4C]; b2 f32[C];
+ * h1 T[B][H][W][4C] = GELU(linear1(LN2(x))); w9 f32[9][4C]; bdw f32[4C]; W2_fm fragment-major T[C][4C]; b2 f32[C];
  * x f32 rows of C (stride ld), updated in place.  The conv output never reaches HBM. */
-int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2,
+int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2_fm,
                           const float* b2, float* x, int ld, int B, int H, int W, int C,
                           uf_dtype dtype, void* stream);
 
@@ -126,17 +138,19 @@ typedef struct uf_block_params {
     const float* norm1_b;   /* norm1.bias */
     const float* modulator; /* modulator.weight (64,C) or NULL */
     const float* rpb_dense; /* (heads,64,64) gathered from attn.relative_position_bias_table */
-    const void* wqkv;       /* T (3C,C): attn.qkv.to_q.weight ; attn.qkv.to_kv.weight */
+    const float* rpb_fm;    /* the same values, fragment-major (heads,4,4,64,4) */
+    const void* wqkv_fm;    /* T (3C,C) fragment-major: attn.qkv.to_q.weight ; attn.qkv.to_kv.weight */
     const float* bqkv;      /* (3C) */
-    const void* wproj;      /* T (C,C) attn.proj.weight */
+    const void* wproj;      /* T (C,C) attn.proj.weight, row-major (3-kernel fallback path) */
+    const void* wproj_fm;   /* T (C,C) fragment-major */
     const float* bproj;     /* (C) */
     const float* norm2_w;
     const float* norm2_b;
-    const void* w1;         /* T (4C,C) mlp.linear1.0.weight */
+    const void* w1_fm;      /* T (4C,C) fragment-major mlp.linear1.0.weight */
     const float* b1;        /* (4C) */
     const float* wdw9;      /* (9,4C) tap-major repack of mlp.dwconv.0.weight (4C,1,3,3) */
     const float* bdw;       /* (4C) */
-    const void* w2;         /* T (C,4C) mlp.linear2.0.weight */
+    const void* w2_fm;      /* T (C,4C) fragment-major mlp.linear2.0.weight */
     const float* b2;        /* (C) */
     int32_t shift;          /* 0 or 4, decided at construction (model.py:1030, :863-866) */
     int32_t heads;

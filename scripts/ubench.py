@@ -41,5 +41,61 @@ def main():
                   f"ln_fc1 {t_f:7.1f} us ({2 * M * 4 * C * C / t_f / 1e6:6.1f} TF/s)", flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and (len(sys.argv) < 2 or sys.argv[1] == "lngemm"):
     main()
+
+
+def bench_blocks():
+    """attention half / LeFF half of one block on the big stages, with the ablation env vars."""
+    import ctypes
+    from uformer_amd import _lib, model, packing
+    lib = _lib.load()
+    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 64, 128, 4), (16, 256, 64, 2)):
+        blk = model.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
+        bp = blk._pack(torch.bfloat16)
+        M = B * H * H
+        x = torch.randn(M, C, device="cuda")
+        nbytes = lib.uf_block_workspace_bytes(M, C, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        ta = timeit(lambda: lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st))
+        tl = timeit(lambda: lib.uf_leff_fwd(bp, x.data_ptr(), C, B, H, H, C, 1, ws.data_ptr(), nbytes, st))
+        print(f"A={os.environ.get('UF_ATTNBLK_DBG', '0')} L={os.environ.get('UF_LEFF2_DBG', '0')} M={M} C={C}: attn_half {ta:7.1f} us   leff_half {tl:7.1f} us", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "blocks":
+    bench_blocks()
+
+
+def bench_stamps():
+    """Phase timestamps of attn_block (cycle counter of wave 0..N of every 64th window)."""
+    from uformer_amd import _lib, model
+    lib = _lib.load()
+    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 64, 128, 4)):
+        blk = model.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
+        bp = blk._pack(torch.bfloat16)
+        M = B * H * H
+        x = torch.randn(M, C, device="cuda")
+        nbytes = lib.uf_block_workspace_bytes(M, C, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        waves = 8 if C == 512 else 4
+        tb = torch.zeros((M // 64 // 64 + 1) * waves * 8, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        t = tb.cpu().reshape(-1, waves, 8)
+        t0 = t[..., 0].min()
+        print(f"C={C}: stamps relative to first block start, wave 0 of sampled blocks (cycles @100MHz? raw counter units)")
+        for bi in range(min(t.shape[0], 6)):
+            row = t[bi, 0]
+            print(f"  block {bi * 64:5d}: start {int(row[0] - t0):8d} | LN {int(row[1] - row[0]):7d} bar {int(row[2] - row[1]):6d} QKV {int(row[3] - row[2]):7d} "
+                  f"attn {int(row[4] - row[3]):7d} rest-units {int(row[5] - row[4]):7d} bar {int(row[6] - row[5]):6d} proj {int(row[7] - row[6]):7d}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps":
+    bench_stamps()

@@ -325,6 +325,21 @@ def test_samplers_oracle_bigger(dtype):
     check("upsample_256", up.cuda()(xu.cuda(), dtype), O.upsample(xu.to(dtype).float(), pu, ""), dtype)
 
 
+@pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("N,K", [(48, 16), (96, 32), (768, 256), (512, 2048)])
+def test_fragment_major_packing_bit_exact(ops, dtype, N, K):
+    """uf_pack_weight_fm (device) == packing.pack_frag (host formula) == the layout documented in the header."""
+    from uformer_amd import packing
+    w = torch.randn(N, K, generator=torch.Generator().manual_seed(N + K)).to(dtype)
+    dev = ops._pack_frag(w.cuda()).cpu()
+    host = packing.pack_frag(w, dtype).reshape(-1)
+    assert torch.equal(dev, host)
+    KS = (K + 31) // 32
+    n, k = N - 3, K - 5                                    # spot-check the closed form
+    off = ((n // 16 * KS + k // 32) * 64 + ((k % 32) // 8) * 16 + n % 16) * 8 + k % 8
+    assert dev[off] == w[n, k]
+
+
 def test_errors_are_loud(ops):
     """No silent fallbacks: CPU tensors, bad shapes and unsupported sizes raise with the library's message."""
     from uformer_amd._lib import UformerHipError

@@ -19,8 +19,8 @@ c_int, c_void_p, c_size_t, c_float_p = C.c_int, C.c_void_p, C.c_size_t, C.c_void
 class BlockParams(C.Structure):
     """``uf_block_params`` (include/uformer_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
-        "norm1_w", "norm1_b", "modulator", "rpb_dense", "wqkv", "bqkv", "wproj", "bproj",
-        "norm2_w", "norm2_b", "w1", "b1", "wdw9", "bdw", "w2", "b2")] + [
+        "norm1_w", "norm1_b", "modulator", "rpb_dense", "rpb_fm", "wqkv_fm", "bqkv", "wproj", "wproj_fm", "bproj",
+        "norm2_w", "norm2_b", "w1_fm", "b1", "wdw9", "bdw", "w2_fm", "b2")] + [
         ("shift", C.c_int32), ("heads", C.c_int32)]
 
 
@@ -44,6 +44,9 @@ SIGNATURES = {
     "uf_last_error": (I, [C.c_char_p, c_size_t]),
     "uf_timing_enable": (I, [I]),
     "uf_timing_report": (I, [C.c_char_p, c_size_t]),
+    "uf_debug_set_tbuf": (I, [P]),
+    "uf_weight_fm_elems": (c_size_t, [I, I]),
+    "uf_pack_weight_fm": (I, [P, P, I, I, I, P]),
     "uf_window_partition": (I, [P, P, I, I, I, I, I, I, P]),
     "uf_window_reverse": (I, [P, P, I, I, I, I, I, I, P]),
     "uf_shift_mask": (I, [P, I, I, I, P]),

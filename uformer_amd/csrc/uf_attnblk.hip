@@ -15,6 +15,8 @@
 // Phase 2  proj: out = O Wp^T (+bias), window_reverse + roll back folded into the store index,
 //          + residual, in place on the f32 stream.
 // HBM traffic of the attention half: x once in, x once out, weights from L2.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "uf_internal.h"
@@ -26,11 +28,12 @@ struct AttnBlkParams {
     float* x; int ld;
     const float* gamma; const float* beta; const float* modulator;
     const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
-    const float* bias_dense;               // f32[heads][64][64]
+    const float* bias_fm;                  // f32[heads][4 qt][4 kt][64 lanes][4]: fragment-major rel-pos bias
     const float* mask; int n_mask;         // optional dense mask (n_mask,64,64)
     const void* Wp; const float* bp;       // T[C][C], f32[C]
     int n_windows, H, W, shift;
     float qscale;
+    unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
 };
 
 template <typename T> struct FragFromAcc;
@@ -62,6 +65,10 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     const int fr = lane & 15, fg = lane >> 4;
     const int bw = blockIdx.x;                      // window index (image-major, as window_partition)
     const int m0 = bw * 64;
+    auto stamp = [&](int k) {
+        if (p.tbuf && lane == 0 && (bw & 63) == 0) p.tbuf[((bw >> 6) * WAVES + wave) * 8 + k] = __builtin_readcyclecounter();
+    };
+    stamp(0);
 
     // ---------------- phase 0: LN1 (+gather, +modulator) -> Xn --------------------------------------
     {
@@ -109,7 +116,9 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
         }
     }
+    stamp(1);
     __syncthreads();
+    stamp(2);
 
     // SW-MSA mask predicate of this window (model.py:924-942), evaluated in registers
     const int nWc = p.W >> 3, nW = (p.H >> 3) * nWc;
@@ -131,15 +140,15 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ak[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
-        // weight rows of this head: q rows h*32+16i+fr, k rows C+.., v rows 2C+..; k offset fg*8
+        // 16-row weight tiles of this head in the fragment-major Wqkv: q tiles h*2+i, k tiles C/16+.., v tiles 2C/16+..
         const T* wrow[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + (size_t)((i >> 1) * C + h * 32 + (i & 1) * 16 + fr) * C + fg * 8;
+        for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;   // fragment-major tiles
         Frag<T> wf[2][6], af[2][4];
         Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
         auto wload = [&](int ks, int slot) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 32);
+            for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
         };
         auto aload = [&](int ks, int slot) {
 #pragma unroll
@@ -171,6 +180,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (u == wave) stamp(3);
         // bias (+ scale on q, model.py:497), then the accumulators ARE the attention operands
         Frag<T> qf[QT], kf[4], vtf[2][2];
         {
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 s[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 mma16(s[kt][j], kf[kt], qf[j]);
             }
-        const float* bh = p.bias_dense + (size_t)h * 4096;
+        const float* bh = p.bias_fm + (size_t)h * 4096 + lane * 4;   // [h][qt][kt][lane][4]
         float inv[QT];
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int k0 = kt * 16 + fg * 4;
-                f32x4 v = s[kt][j] + *reinterpret_cast<const f32x4*>(bh + qi * 64 + k0);
+                f32x4 v = s[kt][j] + *reinterpret_cast<const f32x4*>(bh + ((q0 + j) * 4 + kt) * 256);
                 if (mk) v += *reinterpret_cast<const f32x4*>(mk + qi * 64 + k0);
                 const bool dy = last_r && (((k0 >> 3) >= 4) != q_lo_y);
 #pragma unroll
@@ -254,8 +264,11 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             store4(orow, o[0][j] * inv[j]);
             store4(orow + 16, o[1][j] * inv[j]);
         }
+        if (u == wave) stamp(4);
     }
+    stamp(5);
     __syncthreads();
+    stamp(6);
 
     // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------
     {
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         Frag<T> wf[2][TNW], af[2][TMW];
         auto wload = [&](int ks, int slot) {
 #pragma unroll
-            for (int i = 0; i < TNW; ++i) load_frag(wf[slot][i], Wp + (size_t)((wn * TNW + i) * 16 + fr) * C + ks * 32 + fg * 8);
+            for (int i = 0; i < TNW; ++i) load_frag(wf[slot][i], Wp + (((size_t)(wn * TNW + i) * KS + ks) * 64 + lane) * 8);
         };
         auto aload = [&](int ks, int slot) {
 #pragma unroll
@@ -290,6 +303,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks & 1][i], af[ks & 1][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        stamp(7);
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
             const int tok = window_row_to_token(m0 + (wm * TMW + j) * 16 + fr, p.H, p.W, p.shift);
@@ -330,6 +344,9 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
 
 }  // namespace
 
+static unsigned long long* g_tbuf = nullptr;
+void debug_set_tbuf(void* p) { g_tbuf = (unsigned long long*)p; }
+
 // true when the fused kernel covers (dtype, C, head_dim); otherwise the caller uses the 3-kernel path
 bool attn_block_supported(uf_dtype dtype, int C, int heads) {
     if (heads <= 0 || C != heads * 32) return false;
@@ -341,10 +358,11 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
                       uf_dtype dtype, hipStream_t st) {
     AttnBlkParams p{};
     p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
-    p.Wqkv = bp->wqkv; p.bqkv = bp->bqkv; p.bias_dense = bp->rpb_dense; p.mask = mask; p.n_mask = n_mask;
-    p.Wp = bp->wproj; p.bp = bp->bproj;
+    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.bias_fm = bp->rpb_fm; p.mask = mask; p.n_mask = n_mask;
+    p.Wp = bp->wproj_fm; p.bp = bp->bproj;
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0));
+    p.tbuf = g_tbuf;
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
     if (dtype == UF_BF16) {
         switch (C) {

@@ -96,6 +96,10 @@ extern "C" int uf_timing_report(char* json, size_t n) {
     return (int)out.size();
 }
 
+namespace uf { void debug_set_tbuf(void* p); }
+// development aid: device buffer that instrumented kernels fill with s_memtime stamps (NULL = off)
+extern "C" int uf_debug_set_tbuf(void* p) { uf::debug_set_tbuf(p); return UF_OK; }
+
 extern "C" int uf_version(void) { return UF_ABI_VERSION; }
 
 extern "C" int uf_last_error(char* buf, size_t n) {

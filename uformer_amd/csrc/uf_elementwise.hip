@@ -261,6 +261,19 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
     }
 }
 
+// fragment-major weight packing: out[((ntile*KS + kstep)*64 + fg*16 + fr)*8 + e] = W[ntile*16+fr][kstep*32+fg*8+e]
+template <typename E>
+__global__ void pack_fm_kernel(const E* __restrict__ w, E* __restrict__ out, int N, int K, int KS) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one 8-element group
+    if (idx >= (long long)(N / 16) * KS * 64) return;
+    const int lane = (int)(idx & 63), fr = lane & 15, fg = lane >> 4;
+    const long long blk = idx >> 6;
+    const int ks = (int)(blk % KS), nt = (int)(blk / KS);
+    const int n = nt * 16 + fr, k0 = ks * 32 + fg * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[idx * 8 + e] = (k0 + e < K) ? w[(size_t)n * K + k0 + e] : E(0);
+}
+
 }  // namespace
 
 int launch_layernorm(const float* x, int ld_x, const float* gamma, const float* beta, const float* modulator, void* out,
@@ -331,6 +344,20 @@ static int window_copy(const void* src, void* dst, int B, int H, int W, int C, i
         }
     }
     return check_launch("window op");
+}
+
+extern "C" size_t uf_weight_fm_elems(int N, int K) { return (N <= 0 || K <= 0 || N % 16) ? 0 : (size_t)N * (size_t)((K + 31) / 32 * 32); }
+
+extern "C" int uf_pack_weight_fm(const void* w, void* out, int N, int K, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(w && out, UF_ERR_NULL, "uf_pack_weight_fm: null pointer");
+    UF_REQUIRE(N > 0 && K > 0 && N % 16 == 0, UF_ERR_SHAPE, "uf_pack_weight_fm: N=%d must be a positive multiple of 16, K=%d positive", N, K);
+    const int KS = (K + 31) / 32;
+    const long long groups = (long long)(N / 16) * KS * 64;
+    dim3 grid((unsigned)((groups + 255) / 256));
+    if (dtype == UF_BF16) hipLaunchKernelGGL(pack_fm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)out, N, K, KS);
+    else if (dtype == UF_F32) hipLaunchKernelGGL(pack_fm_kernel<uint32_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)w, (uint32_t*)out, N, K, KS);
+    else { set_error("uf_pack_weight_fm: dtype %d", (int)dtype); return UF_ERR_UNSUPPORTED; }
+    return check_launch("pack_weight_fm");
 }
 
 extern "C" int uf_window_partition(const void* x, void* out, int B, int H, int W, int C, int shift, int elem_bytes, void* stream) {

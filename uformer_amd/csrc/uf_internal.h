@@ -32,6 +32,7 @@ struct GemmParams {
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream);
 
 // fused attention half (uf_attnblk.hip)
+void debug_set_tbuf(void* p);
 bool attn_block_supported(uf_dtype dtype, int C, int heads);
 int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, const float* mask, int n_mask,
                       uf_dtype dtype, hipStream_t st);

@@ -11,6 +11,8 @@
 //   3. MFMA: out[pixels][C] += tile x W2[:, chunk]^T, W2 fragments streamed L2 -> registers (issued
 //      before the stencil so the round trip hides under it), accumulators stay in registers.
 // The conv output (the largest tensor of the block, 4C per token) never goes to HBM.
+#include <stdlib.h>
+
 #include "uf_internal.h"
 
 namespace uf {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < TNW; ++i)
-                load_frag(wf[ks][i], W2 + (size_t)((wn * TNW + i) * 16 + fr) * HID + ch * KC + ks * 32 + fg * 8);
+                load_frag(wf[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + ch * 2 + ks) * 64 + lane) * 8);   // fragment-major W2
         __builtin_amdgcn_sched_barrier(0);
 
         // (b) depthwise 3x3 + bias + GELU from the halo tile -> operand tile

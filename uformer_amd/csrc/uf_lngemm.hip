@@ -28,7 +28,6 @@ struct LnGemmParams {
     int H, W, windowed, shift;
     void* out; int ldo;              // EP_GELU: T[M][ldo]
     void* q; void* k; void* vt; int heads, hd; float qscale;  // EP_QKV
-    int dbg;                         // UF_LNGEMM_DBG ablation bits (1: no LN loads, 2: no MFMA loop, 4: no stores)
 };
 
 enum { EP_QKV = 0, EP_GELU = 1 };
@@ -60,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
         static_assert(NP % U == 0, "pass batching");
         const int sub = tid % LPR;
 #pragma unroll 1
-        for (int r0 = (p.dbg & 1) ? BM : 0; r0 < BM; r0 += RPP * U) {
+        for (int r0 = 0; r0 < BM; r0 += RPP * U) {
             f32x4 v[U][V4];
             bool live[U];
 #pragma unroll
@@ -112,14 +111,16 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
     const T* Wt = reinterpret_cast<const T*>(p.Wt);
     const int Cq = p.heads * p.hd;  // == C for the QKV projection
     // Weight loads are UNCONDITIONAL (hipcc wraps a guarded load in an exec-masked branch with a
-    // vmcnt(0) wait, which would serialise the prefetch ring): rows past N are clamped to a valid
-    // row -- their products land in accumulator columns that are never stored -- and for C = 16 the
-    // k-slots 16..31 read slot 0 again and are multiplied by the zeroed activation fragment.
+    // vmcnt(0) wait, which would serialise the prefetch ring): tiles past N are clamped to a valid
+    // tile -- their products land in accumulator columns that are never stored.  For C = 16 the packed
+    // k-slots 16..31 are zero padding.
+    // weights are FRAGMENT-MAJOR (uf_pack_weight_fm): [n-tile][k-step][lane][8] -> one wave-level load
+    // reads 1 KiB (bf16) contiguous instead of 16 half cache lines at a power-of-two stride
     const T* wrow[4];
     Frag<T> wf[RING][4];
     auto wload = [&](int ks, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 32);
+        for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
     };
     // first RING-1 k-steps of a unit's weights; issued for unit u+4 BEFORE the epilogue of unit u so
     // the L2 round trip hides under the epilogue instead of stalling the next unit's first MFMAs.
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
         const int nb = (g0 + u / MH) * 64;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int n = nb + i * 16 + fr;
-            n = n < p.N ? n : p.N - 1;
-            wrow[i] = Wt + (size_t)n * C + (fg * 8 < C ? fg * 8 : 0);
+            int tile = (nb >> 4) + i;                       // clamp: tiles past N are computed but never stored
+            tile = tile < (p.N >> 4) ? tile : (p.N >> 4) - 1;
+            wrow[i] = Wt + ((size_t)tile * KS * 64 + lane) * 8;
         }
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s)
@@ -185,8 +186,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if (p.dbg & 2) {
-        } else if (EP != EP_QKV || nv == 4) kloop(std::integral_constant<int, 0>{});
+        if (EP != EP_QKV || nv == 4) kloop(std::integral_constant<int, 0>{});
         else if (nv == 0) kloop(std::integral_constant<int, 1>{});
         else kloop(std::integral_constant<int, 2>{});
         if (u + 4 < n_units) unit_prefetch(u + 4);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                     const int idx = it * 64 + lane;
                     const int r = idx / CPR, cb = idx % CPR;
                     const int m = m0 + mbase + j * 16 + r, n = nbase + cb * EPC;
-                    if (m < p.M && n < p.N && (cb * EPC) / 16 < nv && !(p.dbg & 4)) {
+                    if (m < p.M && n < p.N && (cb * EPC) / 16 < nv) {
                         const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SS + cb * 16);
                         T* dst;
                         if constexpr (EP == EP_QKV) {
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                         const int idx = it * 64 + lane;
                         const int r = idx / CPR, cb = idx % CPR;
                         const int n = nbase + i * 16 + r, m = m0 + mbase + cb * EPC;
-                        if (m < p.M && n < p.N && !(p.dbg & 4)) {
+                        if (m < p.M && n < p.N) {
                             const u32x4 val = *reinterpret_cast<const u32x4*>(stg + r * SS + cb * 16);
                             const int h = t_h[i], d = t_d[i] + r;   // tile i of the unit, channel row r
                             T* dst = reinterpret_cast<T*>(p.vt) + (((size_t)(m >> 6) * p.heads + h) * p.hd + d) * 64 + (m & 63);
@@ -294,9 +294,7 @@ int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     constexpr int smem = BM * (C * SZ + 16) + 4 * 16 * (64 * SZ + 16);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = ln_gemm_kernel<T, C, BM, EP>;
-    static const int dbg_env = getenv("UF_LNGEMM_DBG") ? atoi(getenv("UF_LNGEMM_DBG")) : 0;
-    LnGemmParams p = p_in;
-    p.dbg = dbg_env;
+    const LnGemmParams& p = p_in;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

@@ -61,7 +61,7 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     char* q = w.h1;
     char* k = q + (size_t)M * C * sz;
     char* vt = k + (size_t)M * C * sz;
-    int rc = uf_ln_qkv_fwd(x, ld, p->norm1_w, p->norm1_b, p->modulator, p->wqkv, p->bqkv, q, k, vt, B, H, W, C, heads,
+    int rc = uf_ln_qkv_fwd(x, ld, p->norm1_w, p->norm1_b, p->modulator, p->wqkv_fm, p->bqkv, q, k, vt, B, H, W, C, heads,
                            p->shift, dtype, st);
     if (rc) return rc;
     // softmax(q k^T + bias + mask) v                    (model.py:498-519)
@@ -79,11 +79,11 @@ int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
               hipStream_t st) {
     const int M = B * H * W;
     // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671)
-    int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1, p->b1, w.h1, M, 4 * C, C, dtype, st);
+    int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1_fm, p->b1, w.h1, M, 4 * C, C, dtype, st);
     if (rc) return rc;
     // depthwise 3x3 + GELU over the whole H x W map, linear2, + residual: one kernel, the conv output
     // stays on chip                                      (model.py:659-661, :674-682, :987)
-    return uf_dwconv_linear2_fwd(w.h1, p->wdw9, p->bdw, p->w2, p->b2, x, ld, B, H, W, C, dtype, st);
+    return uf_dwconv_linear2_fwd(w.h1, p->wdw9, p->bdw, p->w2_fm, p->b2, x, ld, B, H, W, C, dtype, st);
 }
 
 }  // namespace

@@ -51,6 +51,18 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def _pack_frag(w: Tensor) -> Tensor:
+    """Row-major nn.Linear weight -> the fragment-major layout the fused kernels stream (uf_pack_weight_fm)."""
+    _dev(w)
+    w = _c(w)
+    N, K = w.shape
+    lib = _lib.load()
+    out = torch.empty(lib.uf_weight_fm_elems(N, K), dtype=w.dtype, device=w.device)
+    with torch.cuda.device(w.device):
+        _lib.check(lib.uf_pack_weight_fm(_ptr(w), _ptr(out), N, K, uf_dtype(w.dtype), _stream()), "uf_pack_weight_fm")
+    return out
+
+
 def _c(t: Tensor, dtype: Optional[torch.dtype] = None) -> Tensor:
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
@@ -162,7 +174,7 @@ def ln_qkv(x: Tensor, gamma: Tensor, beta: Tensor, wqkv: Tensor, bqkv: Tensor, h
     vt = torch.empty((M // 64, heads, hd, 64), dtype=wqkv.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().uf_ln_qkv_fwd(_ptr(x), Cc, _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)),
-                                             _ptr(None if modulator is None else _c(modulator, torch.float32)), _ptr(_c(wqkv)),
+                                             _ptr(None if modulator is None else _c(modulator, torch.float32)), _ptr(_pack_frag(wqkv)),
                                              _ptr(_c(bqkv, torch.float32)), _ptr(q), _ptr(k), _ptr(vt), B, H, W, Cc, heads, shift,
                                              dt, _stream()), "uf_ln_qkv_fwd")
     return q, k, vt
@@ -178,7 +190,7 @@ def ln_linear_gelu(x: Tensor, gamma: Tensor, beta: Tensor, w1: Tensor, b1: Tenso
     out = torch.empty((M, N), dtype=w1.dtype, device=x.device)
     with torch.cuda.device(x.device):
         _lib.check(_lib.load().uf_ln_linear_gelu_fwd(_ptr(x), Cc, _ptr(_c(gamma, torch.float32)), _ptr(_c(beta, torch.float32)),
-                                                     _ptr(_c(w1)), _ptr(_c(b1, torch.float32)), _ptr(out), M, N, Cc, dt, _stream()),
+                                                     _ptr(_pack_frag(w1)), _ptr(_c(b1, torch.float32)), _ptr(out), M, N, Cc, dt, _stream()),
                    "uf_ln_linear_gelu_fwd")
     return out
 
@@ -222,7 +234,7 @@ def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, 
     Cc = out.shape[-1]
     with torch.cuda.device(h1.device):
         _lib.check(_lib.load().uf_dwconv_linear2_fwd(_ptr(h1), _ptr(_c(w9, torch.float32)), _ptr(_c(bdw, torch.float32)),
-                                                     _ptr(_c(w2, h1.dtype)), _ptr(_c(b2, torch.float32)), _ptr(out), Cc, B, H, W, Cc,
+                                                     _ptr(_pack_frag(_c(w2, h1.dtype))), _ptr(_c(b2, torch.float32)), _ptr(out), Cc, B, H, W, Cc,
                                                      dt, _stream()), "uf_dwconv_linear2_fwd")
     return out
 

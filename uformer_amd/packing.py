@@ -22,6 +22,23 @@ def rpb_dense(table: Tensor, index: Tensor) -> Tensor:
     return table.detach()[index.reshape(-1)].reshape(n, n, -1).permute(2, 0, 1).contiguous().float()
 
 
+def pack_frag(w: Tensor, dtype: torch.dtype) -> Tensor:
+    """nn.Linear weight (N,K) -> fragment-major (N/16, ceil(K/32), 4, 16, 8) of ``dtype``: one wave-level
+    MFMA-operand load then reads 1 KiB contiguous (layout formula in include/uformer_hip.h)."""
+    N, K = w.shape
+    KP = (K + 31) // 32 * 32
+    w = w.detach().to(dtype)
+    if KP != K:
+        w = torch.nn.functional.pad(w, (0, KP - K))
+    return w.reshape(N // 16, 16, KP // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
+
+
+def pack_rpb_frag(dense: Tensor) -> Tensor:
+    """(heads,64,64) bias -> (heads,4,4,64,4): [h][qt][kt][lane = fg*16+fr][r] = bias[h][16qt+fr][16kt+4fg+r]."""
+    h = dense.shape[0]
+    return dense.reshape(h, 4, 16, 4, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous().float()
+
+
 def pack_dwconv(w: Tensor) -> Tensor:
     """(C,1,3,3) -> (9,C) tap-major f32."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
@@ -51,16 +68,18 @@ def pack_block(sd: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype
     """Returns (BlockParams, keepalive list).  ``sd`` maps reference keys to tensors on the GPU."""
     f = lambda k: sd[prefix + k].detach().contiguous().float()  # noqa: E731
     t = lambda k: sd[prefix + k].detach().contiguous().to(dtype)  # noqa: E731
+    wqkv = torch.cat([sd[prefix + "attn.qkv.to_q.weight"].detach(), sd[prefix + "attn.qkv.to_kv.weight"].detach()], 0)
+    dense = rpb_dense(sd[prefix + "attn.relative_position_bias_table"], sd[prefix + "attn.relative_position_index"])
     keep: Dict[str, Tensor] = {
         "norm1_w": f("norm1.weight"), "norm1_b": f("norm1.bias"),
-        "rpb_dense": rpb_dense(sd[prefix + "attn.relative_position_bias_table"], sd[prefix + "attn.relative_position_index"]),
-        "wqkv": torch.cat([sd[prefix + "attn.qkv.to_q.weight"].detach(), sd[prefix + "attn.qkv.to_kv.weight"].detach()], 0).contiguous().to(dtype),
+        "rpb_dense": dense, "rpb_fm": pack_rpb_frag(dense),
+        "wqkv_fm": pack_frag(wqkv, dtype),
         "bqkv": torch.cat([sd[prefix + "attn.qkv.to_q.bias"].detach(), sd[prefix + "attn.qkv.to_kv.bias"].detach()], 0).contiguous().float(),
-        "wproj": t("attn.proj.weight"), "bproj": f("attn.proj.bias"),
+        "wproj": t("attn.proj.weight"), "wproj_fm": pack_frag(sd[prefix + "attn.proj.weight"], dtype), "bproj": f("attn.proj.bias"),
         "norm2_w": f("norm2.weight"), "norm2_b": f("norm2.bias"),
-        "w1": t("mlp.linear1.0.weight"), "b1": f("mlp.linear1.0.bias"),
+        "w1_fm": pack_frag(sd[prefix + "mlp.linear1.0.weight"], dtype), "b1": f("mlp.linear1.0.bias"),
         "wdw9": pack_dwconv(sd[prefix + "mlp.dwconv.0.weight"]), "bdw": f("mlp.dwconv.0.bias"),
-        "w2": t("mlp.linear2.0.weight"), "b2": f("mlp.linear2.0.bias"),
+        "w2_fm": pack_frag(sd[prefix + "mlp.linear2.0.weight"], dtype), "b2": f("mlp.linear2.0.bias"),
     }
     if (prefix + "modulator.weight") in sd:
         keep["modulator"] = f("modulator.weight")
