@@ -147,7 +147,9 @@ def main():
                 a_[k_] += r[k_]
         name, dom = max(sym.items(), key=lambda kv: kv[1]["ms"])
         sec = dom["ms"] / 1e3
-        if name.startswith("gemm") or name.startswith("window_attn"):
+        # bound by arithmetic intensity of the kernel's ALGORITHMIC work vs the machine ridge (flop/byte)
+        ridge = MFMA_PEAK_TFLOPS[args.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if dom["bytes"] <= 0 or dom["flops"] / dom["bytes"] >= ridge:
             ach = dom["flops"] / sec / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                                "frac": ach / MFMA_PEAK_TFLOPS[args.dtype], "traffic": None}
@@ -155,6 +157,8 @@ def main():
             ach = dom["bytes"] / sec / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        out["roofline"]["flop_per_byte"] = dom["flops"] / max(dom["bytes"], 1.0)
+        out["roofline"]["achieved_tflops"] = dom["flops"] / sec / 1e12
         out["roofline"].update({"kernel": name, "launches_per_step": dom["launches"] // 3,
                                 "avg_launch_ms": dom["ms"] / dom["launches"], "share_of_gpu_time": dom["ms"] / total_ms,
                                 "gpu_ms_per_step_all_kernels": total_ms / 3})

@@ -22,6 +22,15 @@ for r in rows:
         kind = {"1": "fc1", "2": "qkv", "3": "proj", "4": "fc2", "5": "down", "6": "up"}[e]
         Mm, N, K = dims
         C = {"fc1": K, "qkv": K, "proj": K, "fc2": N}.get(kind)
+    elif sym.startswith("ln_gemm"):
+        kind = "ln_qkv" if "_qkv_" in sym else "ln_fc1"
+        C = dims[2]
+    elif sym.startswith("leff2"):
+        kind = "leff2"
+        C = dims[1]
+    elif sym.startswith("attn_block"):
+        kind = "attn_block"
+        C = dims[1]
     elif sym.startswith("window_attn"):
         M, C = dims[0] * 64, dims[1] * dims[2]
     elif sym.startswith("layernorm"):

@@ -333,7 +333,7 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
         attr_done = true;
     }
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "attn_block_%s %dx%d", sizeof(T) == 2 ? "bf16" : "f32", p.n_windows * 64, C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "attn_block_%s_c%d_nt%d %dx%d", sizeof(T) == 2 ? "bf16" : "f32", C, NT, p.n_windows * 64, C);
     const double M = (double)p.n_windows * 64;
     {
         ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0), M * C * 8.0 + 4.0 * C * C * sizeof(T), st);

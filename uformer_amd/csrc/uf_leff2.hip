@@ -222,7 +222,7 @@ int launch_tile(const Leff2Params& p, hipStream_t st) {
     }
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_t%dx%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", TH, TW, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_t%dx%d_nt%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, TH, TW, NT, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / TH) * (p.W / TW))), dim3(NT), smem, st, p);

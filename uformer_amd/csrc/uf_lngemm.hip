@@ -306,7 +306,7 @@ int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     }
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "ln_gemm_%s_%s_bm%d %dx%dx%d", SZ == 2 ? "bf16" : "f32", EP == EP_QKV ? "qkv" : "fc1", BM, p.M, p.N, C);
+        snprintf(name, sizeof(name), "ln_gemm_%s_%s_c%d_bm%d %dx%dx%d", SZ == 2 ? "bf16" : "f32", EP == EP_QKV ? "qkv" : "fc1", C, BM, p.M, p.N, C);
     const double mn = (double)p.M * p.N;
     {
         ScopedTimer tm(name, 2.0 * mn * C, (double)p.M * C * 4 + (double)p.N * C * SZ + mn * SZ, st);
