@@ -139,6 +139,8 @@ typedef struct uf_block_params {
     const float* modulator; /* modulator.weight (64,C) or NULL */
     const float* rpb_dense; /* (heads,64,64) gathered from attn.relative_position_bias_table */
     const float* rpb_fm;    /* the same values, fragment-major (heads,4,4,64,4) */
+    const float* rpb_tab;   /* (heads,15,15) compact table [dy+7][7-dx] when the bias is Toeplitz (always, for the
+                               reference's relative_position_index), else NULL -> kernels use rpb_fm */
     const void* wqkv_fm;    /* T (3C,C) fragment-major: attn.qkv.to_q.weight ; attn.qkv.to_kv.weight */
     const float* bqkv;      /* (3C) */
     const void* wproj;      /* T (C,C) attn.proj.weight, row-major (3-kernel fallback path) */

@@ -80,7 +80,7 @@ def bench_stamps():
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         waves = 8 if C == 512 else 4
-        tb = torch.zeros((M // 64 // 64 + 1) * waves * 8, dtype=torch.int64, device="cuda")
+        tb = torch.zeros((M // 64 // 64 + 1) * waves * 16, dtype=torch.int64, device="cuda")
         for _ in range(3):
             lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
@@ -88,13 +88,13 @@ def bench_stamps():
         lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(None)
-        t = tb.cpu().reshape(-1, waves, 8)
+        t = tb.cpu().reshape(-1, waves, 16)
         t0 = t[..., 0].min()
         print(f"C={C}: stamps relative to first block start, wave 0 of sampled blocks (cycles @100MHz? raw counter units)")
         for bi in range(min(t.shape[0], 6)):
             row = t[bi, 0]
             print(f"  block {bi * 64:5d}: start {int(row[0] - t0):8d} | LN {int(row[1] - row[0]):7d} bar {int(row[2] - row[1]):6d} QKV {int(row[3] - row[2]):7d} "
-                  f"attn {int(row[4] - row[3]):7d} rest-units {int(row[5] - row[4]):7d} bar {int(row[6] - row[5]):6d} proj {int(row[7] - row[6]):7d}")
+                  f"[pack+S {int(row[8] - row[3]):6d} softmax {int(row[9] - row[8]):6d} PV {int(row[10] - row[9]):6d} store {int(row[4] - row[10]):6d}] rest-units {int(row[5] - row[4]):7d} bar {int(row[6] - row[5]):6d} proj {int(row[7] - row[6]):7d}")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps":

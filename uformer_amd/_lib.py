@@ -19,7 +19,7 @@ c_int, c_void_p, c_size_t, c_float_p = C.c_int, C.c_void_p, C.c_size_t, C.c_void
 class BlockParams(C.Structure):
     """``uf_block_params`` (include/uformer_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
-        "norm1_w", "norm1_b", "modulator", "rpb_dense", "rpb_fm", "wqkv_fm", "bqkv", "wproj", "wproj_fm", "bproj",
+        "norm1_w", "norm1_b", "modulator", "rpb_dense", "rpb_fm", "rpb_tab", "wqkv_fm", "bqkv", "wproj", "wproj_fm", "bproj",
         "norm2_w", "norm2_b", "w1_fm", "b1", "wdw9", "bdw", "w2_fm", "b2")] + [
         ("shift", C.c_int32), ("heads", C.c_int32)]
 

@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256, 4) void window_attn_kernel(const T* __restrict
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) mx = fmaxf(mx, s[kt][qt][j]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = red_xor32<RedMax>(red_xor16<RedMax>(mx));
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -125,8 +124,7 @@ __global__ __launch_bounds__(256, 4) void window_attn_kernel(const T* __restrict
                 s[kt][qt][j] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
+        sum = red_xor32<RedSum>(red_xor16<RedSum>(sum));
         inv[qt] = 1.0f / sum;
     }
 

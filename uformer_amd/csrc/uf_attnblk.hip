@@ -28,7 +28,8 @@ struct AttnBlkParams {
     float* x; int ld;
     const float* gamma; const float* beta; const float* modulator;
     const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
-    const float* bias_fm;                  // f32[heads][4 qt][4 kt][64 lanes][4]: fragment-major rel-pos bias
+    const float* bias_fm;                  // f32[heads][4 qt][4 kt][64 lanes][4]: fragment-major rel-pos bias (general index buffers)
+    const float* rpb_tab;                  // f32[heads][15][15] compact Toeplitz table, x reversed: [dy+7][7-dx]; NULL -> use bias_fm
     const float* mask; int n_mask;         // optional dense mask (n_mask,64,64)
     const void* Wp; const float* bp;       // T[C][C], f32[C]
     int n_windows, H, W, shift;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xn = smem;
     char* Os = smem + 64 * SA;
+    float* Tab = reinterpret_cast<float*>(smem + 2 * 64 * SA);   // [HEADS][225] compact rel-pos bias
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     const int bw = blockIdx.x;                      // window index (image-major, as window_partition)
     const int m0 = bw * 64;
     auto stamp = [&](int k) {
-        if (p.tbuf && lane == 0 && (bw & 63) == 0) p.tbuf[((bw >> 6) * WAVES + wave) * 8 + k] = __builtin_readcyclecounter();
+        if (p.tbuf && lane == 0 && (bw & 63) == 0) p.tbuf[((bw >> 6) * WAVES + wave) * 16 + k] = __builtin_readcyclecounter();
     };
     stamp(0);
 
@@ -94,8 +96,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
-#pragma unroll
-                for (int o = LPR >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                sum = allreduce<RedSum, LPR>(sum);
                 const float mean = sum * (1.0f / C);
                 float sq = 0.f;
 #pragma unroll
@@ -103,8 +104,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                     v[u][i] -= mean;
                     sq += (v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1]) + (v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3]);
                 }
-#pragma unroll
-                for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+                sq = allreduce<RedSum, LPR>(sq);
                 const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
         }
     }
+    if (p.rpb_tab)
+        for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i];
     stamp(1);
     __syncthreads();
     stamp(2);
@@ -206,7 +208,25 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 s[kt][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 mma16(s[kt][j], kf[kt], qf[j]);
             }
-        const float* bh = p.bias_fm + (size_t)h * 4096 + lane * 4;   // [h][qt][kt][lane][4]
+        if (u == wave) stamp(8);
+        // relative-position bias (model.py:500-506).  bias[q][k] depends only on (yq-yk, xq-xk): for this
+        // lane (query column fr, key group fg) the 4 keys of a tile are 4 consecutive dx, and over the
+        // (query tile, key tile) pairs dy takes 7 values -> 7 x 4 table entries per unit, read from the
+        // compact table in LDS instead of 16 KiB of dense bias per (window, head) from L2.
+        const float* bh = p.bias_fm + (size_t)h * 4096 + lane * 4;   // dense fallback: [h][qt][kt][lane][4]
+        f32x4 tb[7];
+        if (p.rpb_tab) {
+            const int dyc = (fr >> 3) - (fg >> 1);
+            const int xb = 7 - (fr & 7) + 4 * (fg & 1);
+            const float* th = Tab + h * 225 + xb;
+#pragma unroll
+            for (int d = 0; d < 7; ++d) {
+                int row = 2 * (q0 + d - 3) + dyc + 7;      // dy + 7 for (query tile - key tile) = q0 + d - 3 ... (d = j - kt + 3)
+                row = row < 0 ? 0 : (row > 14 ? 14 : row);  // rows outside [0,14] belong to unused (j,kt) pairs
+                const float* tr = th + row * 15;
+                tb[d] = f32x4{tr[0], tr[1], tr[2], tr[3]};
+            }
+        }
         float inv[QT];
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
@@ -216,7 +236,9 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
                 const int k0 = kt * 16 + fg * 4;
-                f32x4 v = s[kt][j] + *reinterpret_cast<const f32x4*>(bh + ((q0 + j) * 4 + kt) * 256);
+                f32x4 v = s[kt][j];
+                if (p.rpb_tab) v += tb[j - kt + 3];
+                else v += *reinterpret_cast<const f32x4*>(bh + ((q0 + j) * 4 + kt) * 256);
                 if (mk) v += *reinterpret_cast<const f32x4*>(mk + qi * 64 + k0);
                 const bool dy = last_r && (((k0 >> 3) >= 4) != q_lo_y);
 #pragma unroll
@@ -227,8 +249,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 }
                 s[kt][j] = v;
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = red_xor32<RedMax>(red_xor16<RedMax>(mx));
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
@@ -238,10 +259,10 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                     s[kt][j][r] = e;
                     sum += e;
                 }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum = red_xor32<RedSum>(red_xor16<RedSum>(sum));
             inv[j] = 1.0f / sum;
         }
+        if (u == wave) stamp(9);
         // O^T = V^T P^T ; o[dt][j]: lane query fr, d = 16dt+4fg+r
         f32x4 o[2][QT];
 #pragma unroll
@@ -257,6 +278,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 mma16(o[0][j], vtf[0][sk], pf);
                 mma16(o[1][j], vtf[1][sk], pf);
             }
+        if (u == wave) stamp(10);
         // head merge (model.py:519): O[token][h*32 + d]
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
@@ -320,7 +342,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 
 template <typename T, int C, int NT>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
-    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16);
+    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT>;
     static bool attr_done = false;
@@ -358,11 +380,12 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
                       uf_dtype dtype, hipStream_t st) {
     AttnBlkParams p{};
     p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
-    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.bias_fm = bp->rpb_fm; p.mask = mask; p.n_mask = n_mask;
+    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.bias_fm = bp->rpb_fm; p.rpb_tab = bp->rpb_tab; p.mask = mask; p.n_mask = n_mask;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0));
     p.tbuf = g_tbuf;
+
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
     if (dtype == UF_BF16) {
         switch (C) {

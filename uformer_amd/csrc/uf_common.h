@@ -48,6 +48,36 @@ __device__ __forceinline__ float gelu_fast(float x) {
 template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_erf(x); }
 template <> __device__ __forceinline__ float gelu_t<bf16>(float x) { return gelu_fast(x); }
 
+// ------------------------------------------------------------------------------------
+// cross-lane all-reduce over W consecutive lanes (W = 2..64), entirely on the VALU: DPP quad
+// permutes / row mirrors inside a 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950)
+// across rows.  `__shfl_xor` lowers to ds_bpermute = one LDS round trip per step, which made the
+// softmax and LayerNorm reductions the slowest part of the fused kernels.
+// ------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float x) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(x), CTRL, 0xF, 0xF, true));
+}
+struct RedSum { static __device__ __forceinline__ float f(float a, float b) { return a + b; } };
+struct RedMax { static __device__ __forceinline__ float f(float a, float b) { return fmaxf(a, b); } };
+template <class Op> __device__ __forceinline__ float red_xor16(float x) {   // combine with lane ^ 16
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <class Op> __device__ __forceinline__ float red_xor32(float x) {   // combine with lane ^ 32
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return Op::f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+template <class Op, int W> __device__ __forceinline__ float allreduce(float x) {
+    if constexpr (W >= 2) x = Op::f(x, dpp_mov<0xB1>(x));     // quad_perm [1,0,3,2]
+    if constexpr (W >= 4) x = Op::f(x, dpp_mov<0x4E>(x));     // quad_perm [2,3,0,1]
+    if constexpr (W >= 8) x = Op::f(x, dpp_mov<0x141>(x));    // row_half_mirror
+    if constexpr (W >= 16) x = Op::f(x, dpp_mov<0x140>(x));   // row_mirror
+    if constexpr (W >= 32) x = red_xor16<Op>(x);
+    if constexpr (W >= 64) x = red_xor32<Op>(x);
+    return x;
+}
+
 // 8 operand elements of type T (one MFMA k-slot group per lane)
 template <typename T> struct Frag;
 template <> struct Frag<bf16> {

@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)src * ld_x + (i * LPR + sub) * 4);
         sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
-#pragma unroll
-    for (int o = LPR >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = allreduce<RedSum, LPR>(sum);
     const float mean = sum * (1.0f / C);
     float sq = 0.f;
 #pragma unroll
@@ -66,8 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         v[i] -= mean;
         sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
     }
-#pragma unroll
-    for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = allreduce<RedSum, LPR>(sq);
     const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
     if (!live) return;
 #pragma unroll
@@ -246,12 +244,9 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
             a2 += (v[0] * w2[0] + v[1] * w2[1]) + (v[2] * w2[2] + v[3] * w2[3]);
         }
     }
-#pragma unroll
-    for (int o = LPP >> 1; o > 0; o >>= 1) {
-        a0 += __shfl_xor(a0, o);
-        a1 += __shfl_xor(a1, o);
-        a2 += __shfl_xor(a2, o);
-    }
+    a0 = allreduce<RedSum, LPP>(a0);
+    a1 = allreduce<RedSum, LPP>(a1);
+    a2 = allreduce<RedSum, LPP>(a2);
     if (live && sub < 3) {
         const float a = sub == 0 ? a0 : (sub == 1 ? a1 : a2);
         const size_t o = ((size_t)b * 3 + sub) * H * W + (size_t)yh * W + xw;

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
-#pragma unroll
-                for (int o = LPR >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                sum = allreduce<RedSum, LPR>(sum);
                 const float mean = sum * (1.0f / C);
                 float sq = 0.f;
 #pragma unroll
@@ -86,8 +85,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                     v[u][i] -= mean;
                     sq += (v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1]) + (v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3]);
                 }
-#pragma unroll
-                for (int o = LPR >> 1; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+                sq = allreduce<RedSum, LPR>(sq);
                 const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {

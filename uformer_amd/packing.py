@@ -39,6 +39,22 @@ def pack_rpb_frag(dense: Tensor) -> Tensor:
     return dense.reshape(h, 4, 16, 4, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous().float()
 
 
+def pack_rpb_table(dense: Tensor):
+    """(heads,64,64) bias -> compact (heads,15,15) table T[h][dy+7][7-dx] with dy = yq-yk, dx = xq-xk, if the bias is
+    Toeplitz in (dy,dx) (true for the reference's relative_position_index, model.py:467-477); else None."""
+    h = dense.shape[0]
+    c = torch.arange(8, device=dense.device)
+    ys, xs = torch.meshgrid(c, c, indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    row = (ys[:, None] - ys[None, :] + 7)          # (64,64) dy+7
+    pos = (7 - (xs[:, None] - xs[None, :]))        # (64,64) 7-dx
+    tab = torch.zeros(h, 15, 15, dtype=torch.float32, device=dense.device)
+    tab[:, row, pos] = dense.float()
+    if not torch.equal(tab[:, row, pos], dense.float()):
+        return None
+    return tab.contiguous()
+
+
 def pack_dwconv(w: Tensor) -> Tensor:
     """(C,1,3,3) -> (9,C) tap-major f32."""
     return w.detach().reshape(w.shape[0], 9).t().contiguous().float()
@@ -83,6 +99,9 @@ def pack_block(sd: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype
     }
     if (prefix + "modulator.weight") in sd:
         keep["modulator"] = f("modulator.weight")
+    tab = pack_rpb_table(dense)
+    if tab is not None:
+        keep["rpb_tab"] = tab
     bp = _lib.BlockParams()
     for name, _ in _lib.BlockParams._fields_:
         if name in ("shift", "heads"):
