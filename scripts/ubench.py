@@ -99,3 +99,36 @@ def bench_stamps():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps":
     bench_stamps()
+
+
+def bench_stamps_leff2():
+    from uformer_amd import _lib, model
+    lib = _lib.load()
+    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 64, 128, 4), (16, 256, 64, 2)):
+        blk = model.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
+        bp = blk._pack(torch.bfloat16)
+        M = B * H * H
+        x = torch.randn(M, C, device="cuda")
+        nbytes = lib.uf_block_workspace_bytes(M, C, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        nblk = M // 64
+        tb = torch.zeros((nblk // 64 + 1) * 16 * 4, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            lib.uf_leff_fwd(bp, x.data_ptr(), C, B, H, H, C, 1, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        lib.uf_leff_fwd(bp, x.data_ptr(), C, B, H, H, C, 1, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        t = tb.cpu().reshape(-1, 16, 4).float()[:4]
+        n = 4 * C // 64 + 1
+        act = t[..., 0] > 0
+        pr = act & (t[..., 2] > 0)
+        co = act & (t[..., 2] == 0)
+        print(f"leff2 C={C}: per iteration (cycles), producers work {t[..., 0][pr].mean() / n:.0f} wait {t[..., 1][pr].mean() / n:.0f} | "
+              f"consumers work {t[..., 0][co].mean() / n:.0f} wait {t[..., 1][co].mean() / n:.0f}   ({n} iterations, {int(pr.sum()) // 4} producer waves)")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps2":
+    bench_stamps_leff2()

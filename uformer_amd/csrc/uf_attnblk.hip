@@ -368,6 +368,7 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
 
 static unsigned long long* g_tbuf = nullptr;
 void debug_set_tbuf(void* p) { g_tbuf = (unsigned long long*)p; }
+unsigned long long* debug_get_tbuf() { return g_tbuf; }
 
 // true when the fused kernel covers (dtype, C, head_dim); otherwise the caller uses the 3-kernel path
 bool attn_block_supported(uf_dtype dtype, int C, int heads) {

@@ -78,6 +78,15 @@ template <class Op, int W> __device__ __forceinline__ float allreduce(float x) {
     return x;
 }
 
+// Workgroup barrier for data exchanged through LDS only.  `__syncthreads()` also waits for every
+// outstanding GLOBAL load (s_waitcnt vmcnt(0)), which kills software prefetch across the barrier; this
+// form waits for LDS traffic only and leaves global loads in flight.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // 8 operand elements of type T (one MFMA k-slot group per lane)
 template <typename T> struct Frag;
 template <> struct Frag<bf16> {

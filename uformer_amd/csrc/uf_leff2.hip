@@ -6,8 +6,8 @@
 // SPATIAL tile of TH x TW pixels and walks over the 4C hidden channels in chunks of 64:
 //   1. the (TH+2) x (TW+2) halo tile of the chunk is staged in LDS (zero outside the image =
 //      the convolution's zero padding); loads for chunk c+1 are issued before the stencil of chunk c;
-//   2. stencil + bias + GELU on the VALU: a thread owns 8 channels x a short column strip, taps in
-//      registers, and writes the MFMA operand tile [pixels][64] to LDS;
+//   2. stencil + bias + GELU on the VALU: a thread owns 8 channels x a 2-row column strip, taps from an
+//      LDS table, and writes the MFMA operand tile [pixels][64] to LDS;
 //   3. MFMA: out[pixels][C] += tile x W2[:, chunk]^T, W2 fragments streamed L2 -> registers (issued
 //      before the stencil so the round trip hides under it), accumulators stay in registers.
 // The conv output (the largest tensor of the block, 4C per token) never goes to HBM.
@@ -24,6 +24,7 @@ struct Leff2Params {
     const void* W2; const float* b2;    // T [C][4C], f32 [C]
     float* x; int ld;               // residual stream rows, in place
     int B, H, W;
+    unsigned long long* tbuf;   // optional per-role cycle totals of sampled blocks (uf_debug_set_tbuf)
 };
 
 constexpr int KC = 64;  // hidden channels per chunk
@@ -46,31 +47,36 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-template <typename T, int C, int TH, int TW, int NT>
-__global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
-    constexpr int WAVES = NT / 64;
+// Wave-specialised version.  512 threads = 8 waves; the hardware places waves w and w+4 of a workgroup
+// on the same SIMD, so every SIMD hosts one PRODUCER wave (0-3: depthwise stencil + GELU, pure VALU/LDS)
+// and one CONSUMER wave (4-7: halo + tap + W2 traffic, MFMAs, epilogue).  The VALU and matrix pipes of a
+// SIMD run concurrently for two different waves, so the stencil of chunk i overlaps the MFMAs of chunk
+// i-1; halo tile, tap table and operand tile are double-buffered in LDS, one barrier per chunk.
+template <typename T, int C, int NP>
+__global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(const Leff2Params p) {
+    constexpr int SR = 8 / NP;                    // rows of the column strip one producer thread convolves (NP = 4 or 8 producer waves)
     constexpr int SZ = sizeof(T);
-    constexpr int BM = TH * TW;                   // pixels per block (64 or 128)
+    constexpr int TH = 8, TW = 8, BM = 64;
     constexpr int HID = 4 * C;
-    constexpr int NCH = HID / KC;                 // chunks
-    constexpr int HW_ = TW + 2, HT = (TH + 2) * HW_;  // halo tile
+    constexpr int NCH = HID / KC;                 // 64-channel chunks
+    constexpr int HW_ = TW + 2, HT = (TH + 2) * HW_;  // 10 x 10 halo tile
     constexpr int SH = KC * SZ + 16;              // LDS row stride, halo tile [HT][KC]
     constexpr int SAT = KC * SZ + 16;             // LDS row stride, operand tile [BM][KC]
-    constexpr int CPP = KC * SZ / 16;             // 16-byte chunks per pixel per channel chunk
-    constexpr int NLD = (HT * CPP + NT - 1) / NT;   // staged 16-byte loads per thread
-    constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;   // wave grid over (pixels, out channels)
-    constexpr int TMW = (BM / 16) / WM, TNW = (C / 16) / WN;       // 16x16 tiles per wave
-    constexpr int SR = BM * 8 / NT;               // rows of the column strip a thread convolves
-    static_assert(TMW >= 1 && TNW >= 1 && TMW * TNW <= 32, "accumulator budget");
+    constexpr int CPP = KC * SZ / 16;             // 16-byte pieces per pixel per chunk
+    constexpr int NLD = (HT * CPP + 255) / 256;   // staged 16-byte loads per consumer thread
+    constexpr int WN = (C / 16) < 4 ? (C / 16) : 4, WM = 4 / WN;   // consumer wave grid (pixels x out channels)
+    constexpr int TMW = 4 / WM, TNW = (C / 16) / WN;               // 16x16 tiles per consumer wave
+    constexpr int HS_BYTES = HT * SH, AT_BYTES = BM * SAT, WL_BYTES = 10 * KC * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Hs = smem;                              // halo tile
-    char* At = smem + HT * SH;                    // MFMA operand tile
-    float* Wl = reinterpret_cast<float*>(smem + HT * SH + BM * SAT);   // taps [9][64] + bias [64] of the chunk
+    char* Hs0 = smem;                             // halo tiles [2]
+    char* At0 = smem + 2 * HS_BYTES;              // operand tiles [2]
+    char* Wl0 = smem + 2 * HS_BYTES + 2 * AT_BYTES;   // taps [9][64] + bias [64], [2]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave < NP;
+    const int ct = tid - NP * 64;                 // consumer thread index (0..255) when !producer
     const int fr = lane & 15, fg = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
     const int bt = blockIdx.x;
     const int b = bt / (tiles_x * tiles_y), tr = bt - b * (tiles_x * tiles_y);
@@ -78,43 +84,104 @@ __global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
     const T* h1 = reinterpret_cast<const T*>(p.h1) + (size_t)b * p.H * p.W * HID;
     const T* W2 = reinterpret_cast<const T*>(p.W2);
 
-    // ---- staging bookkeeping: which halo pixel / 16-byte piece each of this thread's loads covers ----
+    if (producer) {
+        // ------------------------------ producers: stencil ------------------------------------------
+        // a thread owns 8 channels x SR rows of one tile column; the 3 taps of a column come from the LDS tap
+        // table (same address for all pixels of a channel group: broadcast).  Measured alternatives that were
+        // slower: 8 producer waves (LDS-read bound, no gain) and wave-uniform taps via scalar loads (s_load
+        // shares lgkmcnt with the LDS reads and 72 taps exceed the SGPR budget: 2x slower).
+        const int cvec = tid & 7, sx = (tid >> 3) & 7, sy0 = (tid >> 6) * SR;
+        lds_barrier();                                                          // B0: halo(0), taps(0) staged
+        unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
+#pragma unroll 1
+        for (int i = 0; i <= NCH; ++i) {
+            if (i < NCH) {
+                const char* Hs = Hs0 + (i & 1) * HS_BYTES;
+                const float* Wl = reinterpret_cast<const float*>(Wl0 + (i & 1) * WL_BYTES);
+                char* At = At0 + (i & 1) * AT_BYTES;
+                float o[SR][8];
+#pragma unroll
+                for (int r = 0; r < SR; ++r)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[r][k] = Wl[9 * KC + cvec * 8 + k];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float wk[3][8];
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) wk[ky][k] = Wl[(ky * 3 + kx) * KC + cvec * 8 + k];
+#pragma unroll
+                    for (int r = -1; r <= SR; ++r) {      // halo row (sy0 + r + 1) feeds output rows r+1-ky
+                        float f[8];
+                        cvt8<T>(Hs + ((sy0 + r + 1) * HW_ + sx + kx) * SH + cvec * 8 * SZ, f);
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int orow = r + 1 - ky;
+                            if (orow < 0 || orow >= SR) continue;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) o[orow][k] = fmaf(f[k], wk[ky][k], o[orow][k]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < SR; ++r) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) o[r][k] = gelu_t<T>(o[r][k]);
+                    put8(reinterpret_cast<T*>(At + ((sy0 + r) * TW + sx) * SAT) + cvec * 8, o[r]);
+                }
+            }
+            t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
+            lds_barrier();
+            t1 = __builtin_readcyclecounter(); tbar += t1 - t0; t0 = t1;
+        }
+        if (p.tbuf && lane == 0 && (bt & 63) == 0) { p.tbuf[((bt >> 6) * 16 + wave) * 4] = tw; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 1] = tbar; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 2] = producer; }
+        return;
+    }
+
+    // ---------------------------------- consumers ----------------------------------------------------
+    const int cw = wave - NP;
+    const int wm = cw / WN, wn = cw % WN;
+    // staging bookkeeping: which halo pixel / 16-byte piece each of this thread's loads covers
     u32x4 stage[NLD];
-    int s_off[NLD];        // element offset of the clamped source pixel (without the chunk offset)
-    bool s_ok[NLD];        // inside the image (else zero = conv padding)
-    int s_lds[NLD];        // LDS byte offset, -1 if this thread has no load in that slot
+    int s_off[NLD];
+    bool s_ok[NLD];
+    int s_lds[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int idx = tid + NT * i;
+        const int idx = ct + 256 * i;
         const int hp = idx / CPP, piece = idx - hp * CPP;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-        s_ok[i] = idx < HT * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        s_ok[i] = idx < HT * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;   // else zero = conv padding
         const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
         s_off[i] = (cy * p.W + cx) * HID + piece * (16 / SZ);
         s_lds[i] = idx < HT * CPP ? hp * SH + piece * 16 : -1;
     }
-    auto halo_issue = [&](int ch) {   // unconditional loads from clamped pixels
+    f32x4 wstage;
+    const int wl_row = ct >> 4, wl_c4 = (ct & 15) * 4;    // taps: 10 rows x 64 floats = 160 float4 (ct < 160)
+    auto stage_issue = [&](int ch) {                      // unconditional loads from clamped addresses
 #pragma unroll
         for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(h1 + s_off[i] + ch * KC);
-    };
-    // tap weights + bias of a chunk: 10 rows x 64 floats = 160 float4, one per thread (tid < 160)
-    f32x4 wstage;
-    const int wl_row = tid >> 4, wl_c4 = (tid & 15) * 4;
-    auto halo_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hs + s_lds[i]) = s_ok[i] ? stage[i] : u32x4{0, 0, 0, 0};
-        if (tid < 160) *reinterpret_cast<f32x4*>(Wl + wl_row * KC + wl_c4) = wstage;
-    };
-    auto taps_issue = [&](int ch) {   // rows 0..8 = taps, row 9 = bias (clamped row for idle threads)
         const int row = wl_row < 10 ? wl_row : 9;
         const float* src = row < 9 ? p.w9 + (size_t)row * HID : p.bdw;
         wstage = *reinterpret_cast<const f32x4*>(src + ch * KC + wl_c4);
     };
-
-    // ---- stencil role: 8 channels x SR rows of one column ----
-    const int cvec = tid & 7, sx = (tid >> 3) % TW, sy0 = ((tid >> 3) / TW) * SR;
+    auto stage_store = [&](int ch) {
+        char* Hs = Hs0 + (ch & 1) * HS_BYTES;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hs + s_lds[i]) = s_ok[i] ? stage[i] : u32x4{0, 0, 0, 0};
+        if (ct < 160) *reinterpret_cast<f32x4*>(Wl0 + (ch & 1) * WL_BYTES + (wl_row * KC + wl_c4) * 4) = wstage;
+    };
+    Frag<T> wf[2][TNW];
+    auto w2_issue = [&](int ch) {                          // fragment-major W2: 1 KiB contiguous per wave load
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < TNW; ++i)
+                load_frag(wf[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + ch * 2 + ks) * 64 + lane) * 8);
+    };
 
     f32x4 acc[TNW][TMW];
 #pragma unroll
@@ -122,74 +189,41 @@ __global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
 #pragma unroll
         for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    halo_issue(0);
-    taps_issue(0);
-    halo_store();
-    __syncthreads();
-
+    // Schedule of iteration j (producers run stencil(j) meanwhile):
+    //   (a) store halo/taps of chunk j+1 (loaded during iteration j-1) into buffer (j+1)&1 -- last read by
+    //       the producers in iteration j-1;  (b) issue the loads of chunk j+2 (a whole iteration to land:
+    //       raw barriers do not drain them);  (c) MFMAs of chunk j-1, then issue chunk j's W2 fragments.
+    stage_issue(0);
+    stage_store(0);
+    if (NCH > 1) stage_issue(1);
+    w2_issue(0);
+    lds_barrier();                                         // B0
+    unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-        // (a) issue everything this chunk needs from memory BEFORE the VALU-heavy stencil
-        if (ch + 1 < NCH) { halo_issue(ch + 1); taps_issue(ch + 1); }
-        Frag<T> wf[2][TNW];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TNW; ++i)
-                load_frag(wf[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + ch * 2 + ks) * 64 + lane) * 8);   // fragment-major W2
+    for (int j = 0; j <= NCH; ++j) {
+        if (j + 1 < NCH) stage_store(j + 1);
+        if (j + 2 < NCH) stage_issue(j + 2);
         __builtin_amdgcn_sched_barrier(0);
-
-        // (b) depthwise 3x3 + bias + GELU from the halo tile -> operand tile
-        {
-            float o[SR][8];
+        if (j >= 1) {
+            const char* At = At0 + ((j - 1) & 1) * AT_BYTES;
 #pragma unroll
-            for (int r = 0; r < SR; ++r)
+            for (int ks = 0; ks < 2; ++ks) {
+                Frag<T> af[TMW];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[r][i] = Wl[9 * KC + cvec * 8 + i];
+                for (int jj = 0; jj < TMW; ++jj)
+                    load_frag(af[jj], reinterpret_cast<const T*>(At + ((wm * TMW + jj) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                float wk[3][8];   // the three taps of this column, from LDS (same address across pixels: broadcast)
+                for (int ii = 0; ii < TNW; ++ii)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) wk[ky][i] = Wl[(ky * 3 + kx) * KC + cvec * 8 + i];
-#pragma unroll
-                for (int r = -1; r <= SR; ++r) {       // halo row (sy0 + r + 1) feeds output rows r+1-ky
-                    float f[8];
-                    cvt8<T>(Hs + ((sy0 + r + 1) * HW_ + sx + kx) * SH + cvec * 8 * SZ, f);
-#pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int orow = r + 1 - ky;
-                        if (orow < 0 || orow >= SR) continue;
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) o[orow][i] = fmaf(f[i], wk[ky][i], o[orow][i]);
-                    }
-                }
+                    for (int jj = 0; jj < TMW; ++jj) mma16(acc[ii][jj], wf[ks][ii], af[jj]);
             }
-#pragma unroll
-            for (int r = 0; r < SR; ++r) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[r][i] = gelu_t<T>(o[r][i]);
-                put8(reinterpret_cast<T*>(At + ((sy0 + r) * TW + sx) * SAT) + cvec * 8, o[r]);
-            }
+            if (j < NCH) w2_issue(j);                      // fragments for the next iteration's MFMAs
         }
-        __syncthreads();   // operand tile complete; halo tile no longer read
-
-        // (c) next chunk's halo -> LDS, then the MFMAs of this chunk
-        if (ch + 1 < NCH) halo_store();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            Frag<T> af[TMW];
-#pragma unroll
-            for (int j = 0; j < TMW; ++j)
-                load_frag(af[j], reinterpret_cast<const T*>(At + ((wm * TMW + j) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
-#pragma unroll
-            for (int i = 0; i < TNW; ++i)
-#pragma unroll
-                for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks][i], af[j]);
-        }
-        __syncthreads();   // halo tile of chunk ch+1 visible; operand tile free again
+        t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
+        lds_barrier();
+        t1 = __builtin_readcyclecounter(); tbar += t1 - t0; t0 = t1;
     }
+    if (p.tbuf && lane == 0 && (bt & 63) == 0) { p.tbuf[((bt >> 6) * 16 + wave) * 4] = tw; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 1] = tbar; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 2] = producer; }
 
     // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
 #pragma unroll
@@ -199,18 +233,20 @@ __global__ __launch_bounds__(NT, 2) void leff2_kernel(const Leff2Params p) {
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
             const int pm = (wm * TMW + j) * 16 + fr;
-            const int ty = pm / TW, tx = pm - ty * TW;
+            const int ty = pm >> 3, tx = pm & 7;
             float* xp = p.x + ((size_t)(b * p.H + y0 + ty) * p.W + x0 + tx) * p.ld + n;
             *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2);
         }
     }
 }
 
-template <typename T, int C, int TH, int TW, int NT>
-int launch_tile(const Leff2Params& p, hipStream_t st) {
+template <typename T, int C>
+int launch_c(const Leff2Params& p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
-    constexpr int smem = (TH + 2) * (TW + 2) * (KC * SZ + 16) + TH * TW * (KC * SZ + 16) + 10 * KC * 4;
-    auto kern = leff2_kernel<T, C, TH, TW, NT>;
+    // one producer (stencil) wave + one consumer (MFMA) wave per SIMD
+    constexpr int NP = 4;
+    constexpr int smem = 2 * 100 * (KC * SZ + 16) + 2 * 64 * (KC * SZ + 16) + 2 * 10 * KC * 4;
+    auto kern = leff2_kernel<T, C, NP>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -222,27 +258,12 @@ int launch_tile(const Leff2Params& p, hipStream_t st) {
     }
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_t%dx%d_nt%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, TH, TW, NT, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, NP, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / TH) * (p.W / TW))), dim3(NT), smem, st, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((NP + 4) * 64), smem, st, p);
     }
     return check_launch("leff2");
-}
-
-template <typename T, int C>
-int launch_c(const Leff2Params& p, hipStream_t st) {
-    // tile / block-size choice = what fits 256 unified registers per lane without spilling:
-    //   C >= 256: 8x8 pixels, 8 waves (each wave holds a quarter/eighth of the output channels)
-    //   C  = 64,128: 8x8 pixels, 4 waves;   C <= 32: 8x16 pixels when the row is wide enough
-    if constexpr (C >= 256) {
-        return launch_tile<T, C, 8, 8, 512>(p, st);
-    } else if constexpr (C >= 64) {
-        return launch_tile<T, C, 8, 8, 256>(p, st);
-    } else {
-        if (p.W % 16 == 0) return launch_tile<T, C, 8, 16, 256>(p, st);
-        return launch_tile<T, C, 8, 8, 256>(p, st);
-    }
 }
 
 template <typename T>
@@ -263,6 +284,7 @@ int launch_t(const Leff2Params& p, int C, hipStream_t st) {
 }  // namespace
 }  // namespace uf
 
+namespace uf { unsigned long long* debug_get_tbuf(); }
 using namespace uf;
 
 extern "C" int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2,
@@ -275,6 +297,7 @@ extern "C" int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const floa
                UF_ERR_ALIGN, "uf_dwconv_linear2_fwd: operands must be 16-byte aligned");
     UF_REQUIRE((long long)B * H * W * 4LL * C < 0x7fffffffLL, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: tensor too large for 32-bit indexing");
     Leff2Params p{};
+    p.tbuf = uf::debug_get_tbuf();
     p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
