@@ -132,3 +132,31 @@ def bench_stamps_leff2():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps2":
     bench_stamps_leff2()
+
+
+def bench_stamps_lngemm():
+    from uformer_amd import _lib
+    lib = _lib.load()
+    dt = torch.bfloat16
+    for (M, C) in ((65536, 256), (16384, 512), (65536, 128), (1048576, 64)):
+        x = torch.randn(M, C, device="cuda")
+        g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        w1 = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).to(dt)
+        b1 = torch.zeros(4 * C, device="cuda")
+        for _ in range(3):
+            ops.ln_linear_gelu(x, g, b, w1, b1)
+        tb = torch.zeros((M // 64 // 64 + 2) * 4 * 4, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        ops.ln_linear_gelu(x, g, b, w1, b1)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        t = tb.cpu().reshape(-1, 4, 4).float()
+        t = t[t[:, 0, 3] > 0][:4]
+        nu = t[:, :, 3].mean()
+        print(f"ln_fc1 M={M} C={C}: per wave (cycles): LN phase {t[:, :, 0].mean():.0f} | k-loops total {t[:, :, 1].mean():.0f} epilogues total {t[:, :, 2].mean():.0f} "
+              f"| units/block {nu:.0f} -> per unit: kloop {t[:, :, 1].mean() / (nu / 4):.0f} epilogue {t[:, :, 2].mean() / (nu / 4):.0f}")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps3":
+    bench_stamps_lngemm()

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     if (p.rpb_tab)
         for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i];
     stamp(1);
-    __syncthreads();
+    lds_barrier();
     stamp(2);
 
     // SW-MSA mask predicate of this window (model.py:924-942), evaluated in registers
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         if (u == wave) stamp(4);
     }
     stamp(5);
-    __syncthreads();
+    lds_barrier();
     stamp(6);
 
     // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------

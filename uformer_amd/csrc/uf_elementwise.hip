@@ -166,8 +166,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
     }
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) acc[r][i] = gelu_t<T>(acc[r][i]);
+        gelu_n<T, N>(acc[r]);
         Vec16<T>::store(out + ((size_t)(b * H + y0 + r) * W + xw) * C + c, acc[r]);
     }
 }

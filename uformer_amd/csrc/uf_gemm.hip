@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 for (int j = 0; j < TM; ++j) {
                     f32x4 v = acc[i][j] + b;
                     if constexpr (EP == E_STORE_T_GELU) {
-                        v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]);
+                        gelu4<T>(v);
                     }
                     if constexpr (EP == E_QKV) v *= sc;
                     store4(reinterpret_cast<T*>(stg + (j * 16 + fr) * SROW) + i * 16 + fg * 4, v);

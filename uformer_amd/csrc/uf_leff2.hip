@@ -126,8 +126,7 @@ __global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(cons
                 }
 #pragma unroll
                 for (int r = 0; r < SR; ++r) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) o[r][k] = gelu_t<T>(o[r][k]);
+                    gelu_n<T, 8>(o[r]);
                     put8(reinterpret_cast<T*>(At + ((sy0 + r) * TW + sx) * SAT) + cvec * 8, o[r]);
                 }
             }

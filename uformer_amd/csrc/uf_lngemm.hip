@@ -18,6 +18,7 @@
 #include "uf_internal.h"
 
 namespace uf {
+unsigned long long* debug_get_tbuf();
 namespace {
 
 struct LnGemmParams {
@@ -28,6 +29,7 @@ struct LnGemmParams {
     int H, W, windowed, shift;
     void* out; int ldo;              // EP_GELU: T[M][ldo]
     void* q; void* k; void* vt; int heads, hd; float qscale;  // EP_QKV
+    unsigned long long* tbuf;        // optional cycle stamps (uf_debug_set_tbuf)
 };
 
 enum { EP_QKV = 0, EP_GELU = 1 };
@@ -48,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
     const int fr = lane & 15, fg = lane >> 4;
     char* stg = smem + BM * SA + wave * (16 * SS);
     const int m0 = blockIdx.x * BM;
+    unsigned long long ts0 = __builtin_readcyclecounter(), ts_ln = 0, ts_k = 0, ts_e = 0, tsx;
 
     // ---------------- phase 0: LayerNorm (+gather, +modulator) into LDS -------------------------
     {
@@ -98,7 +101,8 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
+    tsx = __builtin_readcyclecounter(); ts_ln = tsx - ts0; ts0 = tsx;
 
     // ---------------- phase 1: barrier-free walk over 64 x 64 output units -------------------------
     // blockIdx.y splits the 64-wide column groups when M alone gives too few blocks for 256 CUs
@@ -137,6 +141,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
     if (wave < n_units) unit_prefetch(wave);
 #pragma unroll 1
     for (int u = wave; u < n_units; u += 4) {
+        tsx = __builtin_readcyclecounter(); ts_e += tsx - ts0; ts0 = tsx;   // time since the previous k-loop ended = epilogue
         const int mh = u % MH, ng = g0 + u / MH;
         const int nbase = ng * 64, mbase = mh * 64;
         // number of leading n-tiles of this unit that are NOT in the V third (wave-uniform)
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
         else kloop(std::integral_constant<int, 2>{});
         if (u + 4 < n_units) unit_prefetch(u + 4);
         __builtin_amdgcn_sched_barrier(0);
+        tsx = __builtin_readcyclecounter(); ts_k += tsx - ts0; ts0 = tsx;
 
         // per-tile destination info for the q/k/v^T layouts, once per unit (scalar): tile i covers
         // channels [nbase+16i, +16) = 16 consecutive d of ONE head of q, k or v.
@@ -204,7 +210,36 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
             }
         }
 
-        // ---- epilogue A: [token][channel] tiles (q, k, LeFF hidden): one 16-row m-tile per pass ----
+        // ---- epilogue for the LeFF hidden (bf16): no LDS round trip.  A lane holds 4 consecutive channels
+        // (8 bytes) of one token per 16-column tile; v_permlane16_swap between lane groups fg and fg^1 of a
+        // tile pair turns that into 16 contiguous bytes per lane (guide T21), so one store instruction
+        // writes 64 contiguous bytes per token.
+        if constexpr (EP == EP_GELU && sizeof(T) == 2) {
+            f32x4 bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = nbase + i * 16 + fg * 4;
+                bv[i] = *reinterpret_cast<const f32x4*>(p.bias + (n < p.N ? n : p.N - 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + mbase + j * 16 + fr;
+#pragma unroll
+                for (int ip = 0; ip < 4; ip += 2) {              // tile pair (ip, ip+1)
+                    f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
+                    gelu4<T>(va); gelu4<T>(vb);
+                    const unsigned a0 = pack2bf(va[0], va[1]), a1 = pack2bf(va[2], va[3]);
+                    const unsigned b0 = pack2bf(vb[0], vb[1]), b1 = pack2bf(vb[2], vb[3]);
+                    // after the swap: even fg lanes hold 8 channels of tile ip, odd fg lanes 8 channels of tile ip+1
+                    const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
+                    if (m < p.M && n < p.N)
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        } else
+        // ---- epilogue A: [token][channel] tiles (q, k, f32 LeFF hidden): one 16-row m-tile per pass via LDS ----
         if (nv > 0) {
             f32x4 bv[4];
 #pragma unroll
@@ -219,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                     if (i < nv) {
                         f32x4 v = acc[i][j] + bv[i];
                         if constexpr (EP == EP_GELU) {
-                            v[0] = gelu_t<T>(v[0]); v[1] = gelu_t<T>(v[1]); v[2] = gelu_t<T>(v[2]); v[3] = gelu_t<T>(v[3]);
+                            gelu4<T>(v);
                         } else {
                             if (nbase + i * 16 < Cq) v *= p.qscale;  // q = q * scale (model.py:497)
                         }
@@ -284,6 +319,11 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
             }
         }
     }
+    tsx = __builtin_readcyclecounter(); ts_e += tsx - ts0;
+    if (p.tbuf && lane == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0) {
+        unsigned long long* o = p.tbuf + ((blockIdx.x >> 6) * 4 + wave) * 4;
+        o[0] = ts_ln; o[1] = ts_k; o[2] = ts_e; o[3] = n_units;
+    }
 }
 
 template <typename T, int C, int BM, int EP>
@@ -292,7 +332,8 @@ int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     constexpr int smem = BM * (C * SZ + 16) + 4 * 16 * (64 * SZ + 16);
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = ln_gemm_kernel<T, C, BM, EP>;
-    const LnGemmParams& p = p_in;
+    LnGemmParams p = p_in;
+    p.tbuf = debug_get_tbuf();
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
