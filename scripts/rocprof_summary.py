@@ -38,3 +38,20 @@ if n:
         for (k, g), a in sorted(agg.items(), key=lambda kv: -kv[1]["dur"]):
             w.writerow([k, g, a["n"], f"{a['dur'] / a['n'] / 1e3:.2f}"] + [f"{a['c'][c] / a['n']:.0f}" for c in names])
     print(f"wrote {out}_pmc.csv ({len(agg)} kernel/grid rows, counters: {names})")
+
+# GPU idle between consecutive kernels (launch gaps): dispatch timeline from the `kernels` view.
+try:
+    tl = cur.execute("select start, end, name from kernels order by start").fetchall()
+except sqlite3.Error as e:
+    tl = []
+    print("no kernel timeline:", e, [r[0] for r in cur.execute("select name from sqlite_master where type='view'")])
+if tl:
+    busy = sum(e - s0 for s0, e, _ in tl)
+    gaps = [tl[i + 1][0] - tl[i][1] for i in range(len(tl) - 1)]
+    small = [g for g in gaps if 0 <= g < 50_000]          # < 50 us: back-to-back launches inside a forward pass
+    neg = sum(1 for g in gaps if g < 0)
+    with open(out + "_gaps.txt", "w") as f:
+        msg = (f"dispatches {len(tl)}  kernel-busy {busy / 1e6:.3f} ms  gaps<50us: n={len(small)} total {sum(small) / 1e6:.3f} ms "
+               f"mean {sum(small) / max(1, len(small)) / 1e3:.2f} us  overlapping dispatches {neg}")
+        f.write(msg + "\n")
+        print(msg)

@@ -161,3 +161,22 @@ def test_arbitrary_resolution_pad_crop():
     got = torch.masked_select(y, msk.bool()).reshape(1, 3, 200, 136)
     exp = torch.masked_select(ref, msk.bool()).reshape(1, 3, 200, 136)
     compare("expand2square_200x136_f32", got, exp, torch.float32)
+
+
+def test_hires_720p_padded_to_1280(model_b):
+    """BASELINE.json configs[4]: a 1280x720 frame goes through expand2square (test/test_sidd.py:79-92) to 1280x1280
+    (1.64 M tokens at full resolution).  No CPU oracle at this size (minutes); instead: finite, bit-reproducible,
+    cropped back to the frame, and the bf16 path agrees with the f32 path of the same library to >= 60 dB."""
+    cfg, sd, m = model_b
+    img = spec.synth_input(1, 720, 1280, 9)
+    xp, msk = O.expand2square(img, 128.0)
+    assert xp.shape[-2:] == (1280, 1280)
+    mf = build(cfg, sd, torch.float32)
+    with torch.no_grad():
+        x = xp.cuda()
+        yb, yb2, yf = m(x), m(x), mf(x)
+    assert torch.isfinite(yb).all() and torch.equal(yb, yb2)
+    crop = lambda y: torch.masked_select(y.float().cpu(), msk.bool()).reshape(1, 3, 720, 1280)  # noqa: E731
+    ps = O.psnr(crop(yb), crop(yf))
+    REPORT["B_720p_bf16_vs_f32"] = {"max_abs_err": (crop(yb) - crop(yf)).abs().max().item(), "psnr_db": ps}
+    assert ps >= BF16_PSNR
