@@ -182,33 +182,40 @@ constexpr int IP_PX = 4;
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ img, const float* __restrict__ w27,
                                                          const float* __restrict__ bias, float* __restrict__ out, int ld_o, int B,
                                                          int Cin, int H, int W, int E) {
-    const int eg = E / 4, xg = (W + IP_PX - 1) / IP_PX;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)B * H * xg * eg) return;
-    const int e = (int)(idx % eg) * 4;
-    const long long grp = idx / eg;
-    const int x0 = (int)(grp % xg) * IP_PX, yh = (int)((grp / xg) % H), b = (int)(grp / ((long long)xg * H));
+    // grid: x = (pixel strip, channel group) of one image row, y = row, z = image -- no 64-bit index divisions
+    const unsigned eg = E / 4, xg = (W + IP_PX - 1) / IP_PX;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= xg * eg) return;
+    const int e = (int)(idx % eg) * 4, x0 = (int)(idx / eg) * IP_PX;
+    const int yh = blockIdx.y, b = blockIdx.z;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + e);
     f32x4 acc[IP_PX];
 #pragma unroll
     for (int q = 0; q < IP_PX; ++q) acc[q] = bv;
+    // clamped column offsets + 0/1 masks once per strip: loads stay unconditional (a select on the loaded value makes
+    // hipcc sink the load into an exec-masked branch with its own s_waitcnt), 32-bit element offsets
+    int xo[IP_PX + 2];
+    float mx[IP_PX + 2];
+#pragma unroll
+    for (int q = 0; q < IP_PX + 2; ++q) {
+        const int ixr = x0 + q - 1;
+        xo[q] = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
+        mx[q] = (ixr >= 0 && ixr < W) ? 1.0f : 0.0f;
+    }
+    const float* wp = w27 + e;
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* plane = img + ((size_t)b * Cin + ci) * H * W;
+        const float* plane = img + (b * Cin + ci) * (H * W);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iyr = yh + ky - 1;
-            const bool iny = iyr >= 0 && iyr < H;
-            const float* row = plane + (size_t)(iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr)) * W;
+            const float my = (iyr >= 0 && iyr < H) ? 1.0f : 0.0f;
+            const float* row = plane + (iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr)) * W;
             float v[IP_PX + 2];
 #pragma unroll
-            for (int q = 0; q < IP_PX + 2; ++q) {
-                const int ixr = x0 + q - 1;
-                const float pv = row[ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr)];
-                v[q] = (iny && ixr >= 0 && ixr < W) ? pv : 0.0f;
-            }
+            for (int q = 0; q < IP_PX + 2; ++q) v[q] = row[xo[q]] * (mx[q] * my);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(w27 + (size_t)(ci * 9 + ky * 3 + kx) * E + e);
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + (ci * 9 + ky * 3 + kx) * E);
 #pragma unroll
                 for (int q = 0; q < IP_PX; ++q) acc[q] += v[q + kx] * wv;
             }
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
         f32x4 a = acc[q];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = a[i] >= 0.f ? a[i] : 0.01f * a[i];
-        *reinterpret_cast<f32x4*>(out + ((size_t)(b * H + yh) * W + x0 + q) * ld_o + e) = a;
+        *reinterpret_cast<f32x4*>(out + (size_t)((b * H + yh) * W + x0 + q) * ld_o + e) = a;
     }
 }
 
@@ -237,45 +244,54 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
                                                           const float* __restrict__ bias, const float* __restrict__ img,
                                                           float* __restrict__ out, int B, int H, int W, int add_img) {
     constexpr int C2 = LPP * 4;
-    const int strips = (H + OP_R - 1) / OP_R;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid: x = (pixel column, channel group) of one strip of OP_R rows, y = strip, z = image
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int sub = (int)(idx % LPP);
-    long long grp = idx / LPP;
-    const bool live = grp < (long long)B * strips * W;
-    if (!live) grp = 0;
-    const int xw = (int)(grp % W), y0 = (int)((grp / W) % strips) * OP_R, b = (int)(grp / ((long long)W * strips));
-    float a[OP_R][3];
+    const bool live = idx / LPP < (unsigned)W;
+    const int xw = live ? (int)(idx / LPP) : 0, y0 = blockIdx.y * OP_R, b = blockIdx.z;
+    f32x4 acc[OP_R][3];   // per-lane partial sums stay 4 channels wide (pure FMAs); one horizontal add at the end
 #pragma unroll
-    for (int r = 0; r < OP_R; ++r) a[r][0] = a[r][1] = a[r][2] = 0.f;
+    for (int r = 0; r < OP_R; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ro[OP_R + 2];
+    float my[OP_R + 2];
+#pragma unroll
+    for (int hr = 0; hr < OP_R + 2; ++hr) {
+        const int iyr = y0 + hr - 1;
+        ro[hr] = (b * H + (iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr))) * W;
+        my[hr] = (iyr >= 0 && iyr < H) ? 1.0f : 0.0f;
+    }
+    const float* xs = x + sub * 4;
+    const float* ws = w + sub * 4;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const int ixr = xw + kx - 1;
         const int ix = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
-        const bool inx = ixr >= 0 && ixr < W;
+        const float mxk = (ixr >= 0 && ixr < W) ? 1.0f : 0.0f;
         f32x4 wk[3][3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) wk[ky][c] = *reinterpret_cast<const f32x4*>(w + (size_t)(c * 9 + ky * 3 + kx) * C2 + sub * 4);
+            for (int c = 0; c < 3; ++c) wk[ky][c] = *reinterpret_cast<const f32x4*>(ws + (c * 9 + ky * 3 + kx) * C2);
 #pragma unroll
         for (int hr = 0; hr < OP_R + 2; ++hr) {
-            const int iyr = y0 + hr - 1;
-            const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
-            const float inb = (inx && iyr >= 0 && iyr < H) ? 1.0f : 0.0f;   // zero padding, loads unconditional
-            const f32x4 v = inb * *reinterpret_cast<const f32x4*>(x + ((size_t)(b * H + iy) * W + ix) * ld_x + sub * 4);
+            // zero padding by a 0/1 factor, loads unconditional from clamped addresses, 32-bit element offsets
+            const f32x4 v = (my[hr] * mxk) * *reinterpret_cast<const f32x4*>(xs + (size_t)(unsigned)((ro[hr] + ix) * ld_x));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int r = hr - ky;
                 if (r < 0 || r >= OP_R) continue;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a[r][c] += (v[0] * wk[ky][c][0] + v[1] * wk[ky][c][1]) + (v[2] * wk[ky][c][2] + v[3] * wk[ky][c][3]);
+                for (int c = 0; c < 3; ++c) acc[r][c] += v * wk[ky][c];
             }
         }
     }
+    float a[OP_R][3];
 #pragma unroll
     for (int r = 0; r < OP_R; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) a[r][c] = allreduce<RedSum, LPP>(a[r][c]);
+        for (int c = 0; c < 3; ++c) a[r][c] = allreduce<RedSum, LPP>((acc[r][c][0] + acc[r][c][1]) + (acc[r][c][2] + acc[r][c][3]));
     if (live && sub < 3) {
         const float bs = bias[sub];
 #pragma unroll
@@ -432,9 +448,11 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
                                  int H, int W, int E, void* stream) {
     UF_REQUIRE(img && w27 && bias && out, UF_ERR_NULL, "uf_input_proj_fwd: null pointer");
     UF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && E % 4 == 0 && ld_o >= E && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_input_proj_fwd: bad shape");
-    const long long n = (long long)B * H * ((W + IP_PX - 1) / IP_PX) * (E / 4);
+    UF_REQUIRE((long long)B * Cin * H * W < 0x7fffffffLL && (long long)Cin * 9 * E < 0x7fffffffLL, UF_ERR_SHAPE, "uf_input_proj_fwd: image too large for 32-bit indexing");
+    UF_REQUIRE(H <= 65535 && B <= 65535, UF_ERR_SHAPE, "uf_input_proj_fwd: H=%d B=%d exceed the launch grid", H, B);
+    const unsigned nx = (unsigned)((W + IP_PX - 1) / IP_PX) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
-    hipLaunchKernelGGL(input_proj_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
+    hipLaunchKernelGGL(input_proj_kernel, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
     return check_launch("input_proj");
 }
 
@@ -442,13 +460,14 @@ extern "C" int uf_output_proj_fwd(const float* x, int ld_x, const float* w, cons
                                   int B, int H, int W, int C2, int add_img, void* stream) {
     UF_REQUIRE(x && w && bias && out && (!add_img || img), UF_ERR_NULL, "uf_output_proj_fwd: null pointer");
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && ld_x >= C2 && ld_x % 4 == 0, UF_ERR_SHAPE, "uf_output_proj_fwd: bad shape");
+    UF_REQUIRE((long long)B * H * W * ld_x < 0xffffffffLL && H / OP_R < 65535 && B <= 65535, UF_ERR_SHAPE, "uf_output_proj_fwd: tensor too large for 32-bit indexing");
     hipStream_t st = (hipStream_t)stream;
     const long long pix = (long long)B * H * W;
     ScopedTimer tm("output_proj", 54.0 * pix * C2, 4.0 * pix * (C2 + 6), st);
 #define UF_OP_CASE(LPPV)                                                                                          \
     case LPPV * 4: {                                                                                              \
-        const long long n = (long long)B * ((H + OP_R - 1) / OP_R) * W * LPPV;                                          \
-        hipLaunchKernelGGL(output_proj_kernel<LPPV>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld_x, \
+        const unsigned nx = (unsigned)W * LPPV;                                                                   \
+        hipLaunchKernelGGL(output_proj_kernel<LPPV>, dim3((nx + 255) / 256, (H + OP_R - 1) / OP_R, B), dim3(256), 0, st, x, ld_x, \
                            w, bias, img, out, B, H, W, add_img);                                                  \
         break;                                                                                                    \
     }

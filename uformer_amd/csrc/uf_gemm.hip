@@ -308,6 +308,10 @@ template <typename T, int AL, int EP>
 int launch_bn(const GemmParams& p, hipStream_t stream) {
     if (p.N <= 32) return launch_cfg<T, 32, 4, 1, AL, EP>(p, stream);
     if (p.N <= 64) return launch_cfg<T, 64, 2, 2, AL, EP>(p, stream);
+    // deep levels (few tokens, long K): 128x128 tiles leave CUs idle (M=4096, N=512 -> 128 blocks); halve the tile width
+    // until there are two blocks per CU
+    const long long tiles128 = (long long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (EP != E_QKV && tiles128 < 512) return launch_cfg<T, 64, 2, 2, AL, EP>(p, stream);
     return launch_cfg<T, 128, 2, 2, AL, EP>(p, stream);
 }
 
