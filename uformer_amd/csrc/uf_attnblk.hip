@@ -28,14 +28,14 @@ struct AttnBlkParams {
     float* x; int ld;
     const float* gamma; const float* beta; const float* modulator;
     const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
-    const float* bias_fm;                  // f32[heads][4 qt][4 kt][64 lanes][4]: fragment-major rel-pos bias (general index buffers)
-    const float* rpb_tab;                  // f32[heads][15][15] compact Toeplitz table, x reversed: [dy+7][7-dx]; NULL -> use bias_fm
-    const float* mask; int n_mask;         // optional dense mask (n_mask,64,64)
+    const float* rpb_tab;                  // f32[heads][15][15] compact Toeplitz rel-pos bias, x reversed: [dy+7][7-dx]
     const void* Wp; const float* bp;       // T[C][C], f32[C]
     int n_windows, H, W, shift;
     float qscale;
     unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
 };
+
+constexpr float LOG2E = 1.4426950408889634f;
 
 template <typename T> struct FragFromAcc;
 template <> struct FragFromAcc<bf16> {
@@ -116,8 +116,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
         }
     }
-    if (p.rpb_tab)
-        for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i];
+    for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i] * LOG2E;   // scores live in the log2 domain (see softmax)
     stamp(1);
     lds_barrier();
     stamp(2);
@@ -127,7 +126,6 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     const int wi = bw % nW;
     const bool last_r = p.shift > 0 && (wi / nWc) == (p.H >> 3) - 1;
     const bool last_c = p.shift > 0 && (wi % nWc) == nWc - 1;
-    const float* mk = p.mask ? p.mask + (size_t)(bw % p.n_mask) * 4096 : nullptr;
     const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
 
     // ---------------- phase 1: per-unit QKV projection + attention, all in registers -------------------
@@ -190,7 +188,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             const f32x4 bk0 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + 16 + fg * 4);
             const float bv0 = p.bqkv[2 * C + h * 32 + fr], bv1 = p.bqkv[2 * C + h * 32 + 16 + fr];
 #pragma unroll
-            for (int j = 0; j < QT; ++j) FragFromAcc<T>::make(qf[j], (aq[0][j] + bq0) * p.qscale, (aq[1][j] + bq1) * p.qscale);
+            for (int j = 0; j < QT; ++j) FragFromAcc<T>::make(qf[j], (aq[0][j] + bq0) * p.qscale, (aq[1][j] + bq1) * p.qscale);   // qscale carries log2(e)
 #pragma unroll
             for (int j = 0; j < 4; ++j) FragFromAcc<T>::make(kf[j], ak[0][j] + bk0, ak[1][j] + bk1);
 #pragma unroll
@@ -213,9 +211,12 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         // lane (query column fr, key group fg) the 4 keys of a tile are 4 consecutive dx, and over the
         // (query tile, key tile) pairs dy takes 7 values -> 7 x 4 table entries per unit, read from the
         // compact table in LDS instead of 16 KiB of dense bias per (window, head) from L2.
-        const float* bh = p.bias_fm + (size_t)h * 4096 + lane * 4;   // dense fallback: [h][qt][kt][lane][4]
+        // Softmax in the log2 domain: q was scaled by scale*log2(e) and the table by log2(e), so
+        // exp(s - max) = exp2(s' - max') is one v_sub + v_exp per score (no multiply); the SW-MSA mask
+        // (-100, model.py:924-942) becomes -100*log2(e) and is applied only in the windows that have one
+        // (last window row / column of a shifted block): a wave-uniform branch, interior windows skip it.
         f32x4 tb[7];
-        if (p.rpb_tab) {
+        {
             const int dyc = (fr >> 3) - (fg >> 1);
             const int xb = 7 - (fr & 7) + 4 * (fg & 1);
             const float* th = Tab + h * 225 + xb;
@@ -227,35 +228,42 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                 tb[d] = f32x4{tr[0], tr[1], tr[2], tr[3]};
             }
         }
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) s[kt][j] += tb[j - kt + 3];
+        if (last_r || last_c) {
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                const int qi = (q0 + j) * 16 + fr;
+                const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt) {
+                    const int k0 = kt * 16 + fg * 4;
+                    const bool dy = last_r && (((k0 >> 3) >= 4) != q_lo_y);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool k_lo_x = ((k0 & 7) + r) >= 4;
+                        if (dy || (last_c && (k_lo_x != q_lo_x))) s[kt][j][r] += -100.0f * LOG2E;
+                    }
+                }
+            }
+        }
         float inv[QT];
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
-            const int qi = (q0 + j) * 16 + fr;
-            const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
             float mx = -3.0e38f;
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                const int k0 = kt * 16 + fg * 4;
-                f32x4 v = s[kt][j];
-                if (p.rpb_tab) v += tb[j - kt + 3];
-                else v += *reinterpret_cast<const f32x4*>(bh + ((q0 + j) * 4 + kt) * 256);
-                if (mk) v += *reinterpret_cast<const f32x4*>(mk + qi * 64 + k0);
-                const bool dy = last_r && (((k0 >> 3) >= 4) != q_lo_y);
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool k_lo_x = ((k0 & 7) + r) >= 4;
-                    if (dy || (last_c && (k_lo_x != q_lo_x))) v[r] += -100.0f;
-                    mx = fmaxf(mx, v[r]);
-                }
-                s[kt][j] = v;
-            }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][j][r]);
             mx = red_xor32<RedMax>(red_xor16<RedMax>(mx));
             float sum = 0.f;
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __expf(s[kt][j][r] - mx);
+                    const float e = __builtin_amdgcn_exp2f(s[kt][j][r] - mx);
                     s[kt][j][r] = e;
                     sum += e;
                 }
@@ -371,20 +379,22 @@ void debug_set_tbuf(void* p) { g_tbuf = (unsigned long long*)p; }
 unsigned long long* debug_get_tbuf() { return g_tbuf; }
 
 // true when the fused kernel covers (dtype, C, head_dim); otherwise the caller uses the 3-kernel path
-bool attn_block_supported(uf_dtype dtype, int C, int heads) {
+bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads) {
+    // needs the compact (Toeplitz) bias table -- any index buffer built like the reference's (model.py:467-477) has
+    // one -- and no caller-supplied mask; everything else takes the 3-kernel path
+    if (!bp->rpb_tab || user_mask) return false;
     if (heads <= 0 || C != heads * 32) return false;
     if (dtype == UF_BF16) return C == 32 || C == 64 || C == 128 || C == 256 || C == 512;
     return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
 }
 
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, const float* mask, int n_mask,
-                      uf_dtype dtype, hipStream_t st) {
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, hipStream_t st) {
     AttnBlkParams p{};
     p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
-    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.bias_fm = bp->rpb_fm; p.rpb_tab = bp->rpb_tab; p.mask = mask; p.n_mask = n_mask;
+    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
-    p.qscale = (float)(1.0 / sqrt(32.0));
+    p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = g_tbuf;
 
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)

@@ -55,7 +55,7 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     // one fused kernel per window when the shape is covered (head_dim 32): LN1, q/k/v, attention, proj,
     // window_reverse and the residual never leave the CU                       (model.py:951-986)
     static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
-    if (!no_fuse && attn_block_supported(dtype, C, heads)) return launch_attn_block(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, st);
+    if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) return launch_attn_block(p, x, ld, B, H, W, C, dtype, st);
     // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
     // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
