@@ -160,3 +160,69 @@ def bench_stamps_lngemm():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps3":
     bench_stamps_lngemm()
+
+
+def census_report(name, tb, nblocks, wall_us=None):
+    """Decode the per-workgroup census the kernels write at tbuf[65536 + 8 b] (uf_common.h, struct Census)."""
+    import collections
+    c = tb[65536:65536 + nblocks * 8].cpu().reshape(nblocks, 8).numpy()
+    c = c[c[:, 1] > 0]
+    cyc = (c[:, 1] - c[:, 0]).astype(float)
+    rt = (c[:, 3] - c[:, 2]).astype(float) * 10.0          # ns (100 MHz counter)
+    hw = c[:, 4]
+    cu_key = ((hw >> 32) & 0xf) * 4096 + ((hw >> 8) & 0xf) + ((hw >> 12) & 1) * 16 + ((hw >> 13) & 7) * 32   # xcc, cu, sh, se
+    span_ns = (c[:, 3].max() - c[:, 2].min()) * 10.0
+    per_cu = collections.defaultdict(list)
+    for k, a, b in zip(cu_key, c[:, 2], c[:, 3]):
+        per_cu[int(k)].append((int(a), int(b)))
+    maxov = []
+    for k, iv in per_cu.items():
+        ev = sorted([(a, 1) for a, b in iv] + [(b, -1) for a, b in iv])
+        cur = best = 0
+        for _, d in ev:
+            cur += d
+            best = max(best, cur)
+        maxov.append(best)
+    import numpy as np
+    print(f"{name}: {len(c)} workgroups on {len(per_cu)} CUs, workgroups/CU {len(c) / len(per_cu):.2f}, max concurrent per CU: "
+          f"mean {np.mean(maxov):.2f} max {max(maxov)} | block life {rt.mean() / 1e3:.1f} us = {cyc.mean():.0f} cycles -> clock {cyc.sum() / rt.sum():.2f} GHz"
+          f" | kernel span {span_ns / 1e3:.1f} us")
+
+
+def bench_census():
+    from uformer_amd import _lib
+    lib = _lib.load()
+    dt = torch.bfloat16
+    for (B, H, C) in ((16, 64, 256), (16, 32, 512), (16, 64, 128), (16, 128, 128)):
+        M = B * H * H
+        x = torch.randn(M, C, device="cuda")
+        g, b = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        w1 = (torch.randn(4 * C, C, device="cuda") / C ** 0.5).to(dt)
+        b1 = torch.zeros(4 * C, device="cuda")
+        w2 = (torch.randn(C, 4 * C, device="cuda") / (4 * C) ** 0.5).to(dt)
+        b2 = torch.zeros(C, device="cuda")
+        wd = torch.randn(9, 4 * C, device="cuda") * 0.2
+        bd = torch.zeros(4 * C, device="cuda")
+        tb = torch.zeros(65536 + 8 * 8192, dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            h1 = ops.ln_linear_gelu(x, g, b, w1, b1)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        h1 = ops.ln_linear_gelu(x, g, b, w1, b1)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        census_report(f"ln_fc1 M={M} C={C}", tb, 8192)
+        xr = x.clone()
+        for _ in range(2):
+            ops.dwconv_linear2(h1.reshape(B, H, H, 4 * C), wd, bd, w2, b2, xr)
+        tb.zero_()
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        ops.dwconv_linear2(h1.reshape(B, H, H, 4 * C), wd, bd, w2, b2, xr)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        census_report(f"leff2  M={M} C={C}", tb, 8192)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "census":
+    bench_census()

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         if (p.tbuf && lane == 0 && (bw & 63) == 0) p.tbuf[((bw >> 6) * WAVES + wave) * 16 + k] = __builtin_readcyclecounter();
     };
     stamp(0);
+    Census census; census.begin();
 
     // ---------------- phase 0: LN1 (+gather, +modulator) -> Xn --------------------------------------
     {
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         constexpr int V4 = C / (4 * LPR);
         constexpr int RPP = NT / LPR;
         constexpr int NP = 64 / RPP;
-        constexpr int U = (8 / V4) < NP ? (8 / V4) : NP;
+        constexpr int U = (16 / V4) < NP ? (16 / V4) : NP;   // 16 x 16-byte loads in flight per thread
         static_assert(NP >= 1 && NP % U == 0, "pass batching");
         const int sub = tid % LPR;
 #pragma unroll 1
@@ -144,7 +145,10 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         const T* wrow[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;   // fragment-major tiles
-        Frag<T> wf[2][6], af[2][4];
+        // weight fragments come from L2 (>= 500 cycles): ring of WR k-steps in flight where registers allow; the
+        // activation fragments come from LDS, one step ahead is enough
+        constexpr int WR = (SZ == 2 && C >= 128 && C <= 256) ? 3 : 2;
+        Frag<T> wf[WR][6], af[2][4];
         Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
         auto wload = [&](int ks, int slot) {
 #pragma unroll
@@ -159,24 +163,27 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                     load_frag(afq[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
             }
         };
-        wload(0, 0);
+#pragma unroll
+        for (int pf = 0; pf < WR - 1; ++pf)
+            if (pf < KS) wload(pf, pf);
         aload(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) { wload(ks + 1, (ks + 1) & 1); aload(ks + 1, (ks + 1) & 1); }
+            if (ks + WR - 1 < KS) wload(ks + WR - 1, (ks + WR - 1) % WR);
+            if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int s = ks & 1;
+            const int s = ks & 1, sw = ks % WR;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
                 for (int j = 0; j < QT; ++j) {                                                 // q: weight as A operand
-                    if constexpr (QT < 4) mma16(aq[i][j], wf[s][i], afq[s][j]);
-                    else mma16(aq[i][j], wf[s][i], af[s][j]);
+                    if constexpr (QT < 4) mma16(aq[i][j], wf[sw][i], afq[s][j]);
+                    else mma16(aq[i][j], wf[sw][i], af[s][j]);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(ak[i][j], wf[s][2 + i], af[s][j]);         // k: weight as A operand
+                for (int j = 0; j < 4; ++j) mma16(ak[i][j], wf[sw][2 + i], af[s][j]);        // k: weight as A operand
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mma16(av[i][j], af[s][j], wf[s][4 + i]);         // v: activation as A operand
+                for (int j = 0; j < 4; ++j) mma16(av[i][j], af[s][j], wf[sw][4 + i]);        // v: activation as A operand
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -346,6 +353,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
         }
     }
+    census.end(p.tbuf, bw);
 }
 
 template <typename T, int C, int NT>

@@ -80,6 +80,22 @@ template <typename T> __device__ __forceinline__ void gelu4(f32x4& v) {
 }
 
 // ------------------------------------------------------------------------------------
+// debug census (uf_debug_set_tbuf): every workgroup records where and when it ran, so the host can count how many
+// workgroups a CU really held at once and the effective shader clock.  Entry b at tbuf[65536 + 8 b]:
+// {s_memtime start, end, wall_clock64 (100 MHz) start, end, HW_ID | XCC_ID << 32}.
+// ------------------------------------------------------------------------------------
+struct Census {
+    unsigned long long t0, r0;
+    __device__ __forceinline__ void begin() { t0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+    __device__ __forceinline__ void end(unsigned long long* tbuf, unsigned block) const {
+        if (!tbuf || threadIdx.x != 0) return;
+        unsigned long long* o = tbuf + 65536 + (size_t)block * 8;
+        o[0] = t0; o[1] = __builtin_readcyclecounter(); o[2] = r0; o[3] = wall_clock64();
+        o[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    }
+};
+
+// ------------------------------------------------------------------------------------
 // cross-lane all-reduce over W consecutive lanes (W = 2..64), entirely on the VALU: DPP quad
 // permutes / row mirrors inside a 16-lane row, v_permlane16_swap / v_permlane32_swap (gfx950)
 // across rows.  `__shfl_xor` lowers to ds_bpermute = one LDS round trip per step, which made the

@@ -84,6 +84,7 @@ __global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(cons
     const T* h1 = reinterpret_cast<const T*>(p.h1) + (size_t)b * p.H * p.W * HID;
     const T* W2 = reinterpret_cast<const T*>(p.W2);
 
+    Census census; census.begin();
     if (producer) {
         // ------------------------------ producers: stencil ------------------------------------------
         // a thread owns 8 channels x SR rows of one tile column; the 3 taps of a column come from the LDS tap
@@ -236,6 +237,11 @@ __global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(cons
             float* xp = p.x + ((size_t)(b * p.H + y0 + ty) * p.W + x0 + tx) * p.ld + n;
             *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2);
         }
+    }
+    if (ct == 0) {   // census entry written by the first consumer thread (thread 0 is a producer and has returned)
+        Census c2 = census;
+        if (p.tbuf) { unsigned long long* o = p.tbuf + 65536 + (size_t)bt * 8; o[0] = c2.t0; o[1] = __builtin_readcyclecounter(); o[2] = c2.r0; o[3] = wall_clock64();
+            o[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); }
     }
 }
 

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
     const int fr = lane & 15, fg = lane >> 4;
     char* stg = smem + BM * SA + wave * (16 * SS);
     const int m0 = blockIdx.x * BM;
+    Census census; census.begin();
     unsigned long long ts0 = __builtin_readcyclecounter(), ts_ln = 0, ts_k = 0, ts_e = 0, tsx;
 
     // ---------------- phase 0: LayerNorm (+gather, +modulator) into LDS -------------------------
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
         constexpr int V4 = C / (4 * LPR);
         constexpr int RPP = 256 / LPR;                 // rows normalised per pass of the block
         constexpr int NP = BM / RPP;                   // passes
-        constexpr int U = (8 / V4) < NP ? (8 / V4) : NP;  // row groups kept in flight (loads issued together)
+        constexpr int U = (16 / V4) < NP ? (16 / V4) : NP;  // row groups kept in flight (16 x 16-byte loads per thread issued together)
         static_assert(NP % U == 0, "pass batching");
         const int sub = tid % LPR;
 #pragma unroll 1
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
         }
     }
     tsx = __builtin_readcyclecounter(); ts_e += tsx - ts0;
+    census.end(p.tbuf, blockIdx.y * gridDim.x + blockIdx.x);
     if (p.tbuf && lane == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0) {
         unsigned long long* o = p.tbuf + ((blockIdx.x >> 6) * 4 + wave) * 4;
         o[0] = ts_ln; o[1] = ts_k; o[2] = ts_e; o[3] = n_units;
