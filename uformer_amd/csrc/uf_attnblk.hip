@@ -411,7 +411,9 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
             case 32: UF_AB(bf16, 32, 256);
             case 64: UF_AB(bf16, 64, 256);
             case 128: UF_AB(bf16, 128, 256);
-            case 256: UF_AB(bf16, 256, 256);
+            case 256:
+                if (p.n_windows <= 256) UF_AB(bf16, 256, 512);   // one workgroup per CU at most: 8 waves (one head each) instead of 4
+                UF_AB(bf16, 256, 256);
             case 512: UF_AB(bf16, 512, 512);
         }
     } else {

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                     const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
                     if (m < p.M && n < p.N)
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};   // (nontemporal stores measured 3-10 % slower)
                 }
             }
         } else
