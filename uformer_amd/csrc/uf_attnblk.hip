@@ -14,7 +14,11 @@
 //          The head's output goes to the O tile [64][C] in LDS.
 // Phase 2  proj: out = O Wp^T (+bias), window_reverse + roll back folded into the store index,
 //          + residual, in place on the f32 stream.
-// HBM traffic of the attention half: x once in, x once out, weights from L2.
+// Phase 3  (optional, 2-byte operands) first linear of LeFF on the same 64 tokens while their new rows are still in
+//          registers: LN2 (two-pass, cross-wave sums through LDS) -> Xn, then h1 = GELU(Xn W1^T + b1) in 64 x 64 units
+//          with the weight ring / direct-store epilogue of ln_gemm (model.py:987, :657-658).  Saves the separate
+//          ln_fc1 launch, its re-read of x and its LayerNorm phase.
+// HBM traffic of the attention half: x once in, x once out, weights from L2 (+ h1 out when phase 3 runs).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -30,6 +34,9 @@ struct AttnBlkParams {
     const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
     const float* rpb_tab;                  // f32[heads][15][15] compact Toeplitz rel-pos bias, x reversed: [dy+7][7-dx]
     const void* Wp; const float* bp;       // T[C][C], f32[C]
+    const float* gamma2; const float* beta2;   // phase 3 (h1 != NULL): norm2, linear1 (fragment-major T[4C][C]), its bias
+    const void* W1; const float* b1;
+    void* h1;                              // T[B*H*W][4C] or NULL
     int n_windows, H, W, shift;
     float qscale;
     unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
@@ -47,6 +54,90 @@ template <> struct FragFromAcc<float> {
     static __device__ __forceinline__ void make(Frag<float>& f, f32x4 a, f32x4 b) { f.lo = a; f.hi = b; }
 };
 
+template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // balanced pairwise sum, N a power of two
+    static_assert((N & (N - 1)) == 0, "power of two");
+#pragma unroll
+    for (int w = 1; w < N; w *= 2)
+#pragma unroll
+        for (int i = 0; i < N; i += 2 * w) v[i] += v[i + w];
+    return v[0];
+}
+
+// h1[tok(row)][0..4C) = GELU(Xn[row][:] W1^T + b1) for the 64 rows of a window whose normalised operand tile Xn sits in
+// LDS: the barrier-free 64 x 64 unit walk of ln_gemm (uf_lngemm.hip) -- fragment-major weights streamed L2 -> registers
+// through a 3-deep ring pinned with sched_barrier, first k-steps of the next unit issued before the epilogue, and the
+// permlane-widened direct 16-byte stores.  2-byte operand types only.
+template <typename T, int C, int WAVES>
+__device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, const float* b1, T* h1, int m0, int H, int W, int shift,
+                                          int wave, int lane) {
+    constexpr int SZ = sizeof(T), KS = C / 32, RING = 3, N4 = 4 * C, UNITS = N4 / 64;
+    static_assert(SZ == 2, "direct-store epilogue packs bf16 pairs");
+    const int fr = lane & 15, fg = lane >> 4;
+    const T* wrow[4];
+    Frag<T> wf[RING][4];
+    auto wload = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+    };
+    auto unit_prefetch = [&](int u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wrow[i] = W1 + ((size_t)(u * 4 + i) * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int s = 0; s < RING - 1; ++s)
+            if (s < KS) wload(s, s);
+    };
+    size_t rowoff[4];   // h1 row of this lane's token in each 16-row tile (window_reverse + roll back, as the residual rows)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rowoff[j] = (size_t)window_row_to_token(m0 + j * 16 + fr, H, W, shift) * N4;
+    if (wave < UNITS) unit_prefetch(wave);
+#pragma unroll 1
+    for (int u = wave; u < UNITS; u += WAVES) {
+        const int nbase = u * 64;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const char* arow = Xn + fr * SA + fg * 8 * SZ;
+        Frag<T> af[2][4];
+        auto aload = [&](int ks, int slot) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(arow + j * 16 * SA + ks * 32 * SZ));
+        };
+        aload(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + RING - 1 < KS) wload(ks + RING - 1, (ks + RING - 1) % RING);
+            if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], wf[ks % RING][i], af[ks & 1][j]);   // weight as A: lane = 4 channels of one token
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (u + WAVES < UNITS) unit_prefetch(u + WAVES);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(b1 + nbase + i * 16 + fg * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int ip = 0; ip < 4; ip += 2) {
+                f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
+                gelu4<T>(va); gelu4<T>(vb);
+                const unsigned a0 = pack2bf(va[0], va[1]), a1 = pack2bf(va[2], va[3]);
+                const unsigned c0 = pack2bf(vb[0], vb[1]), c1 = pack2bf(vb[2], vb[3]);
+                const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
+                const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
+                const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
+                *reinterpret_cast<u32x4*>(h1 + rowoff[j] + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    }
+}
+
 template <typename T, int C, int NT>
 __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p) {
     constexpr int SZ = sizeof(T);
@@ -61,6 +152,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     char* Xn = smem;
     char* Os = smem + 64 * SA;
     float* Tab = reinterpret_cast<float*>(smem + 2 * 64 * SA);   // [HEADS][225] compact rel-pos bias
+    float* Red = Tab + HEADS * 225;                               // [2][WAVES][64] LN2 partial sums (phase 3)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -349,8 +441,60 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             for (int i = 0; i < TNW; ++i) {
                 const int n = (wn * TNW + i) * 16 + fg * 4;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(p.bp + n);
-                *reinterpret_cast<f32x4*>(xr + n) = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);
+                acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);   // the block's new rows stay in registers
+                *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
             }
+        }
+        if constexpr (SZ == 2) {
+            if (p.h1) {
+                // ---- LN2 of the new rows (model.py:987): two-pass mean / variance; a token's C channels are spread over
+                // the 4 lane groups of a wave (xor 16, 32) and the WN waves of its row group (LDS).  All sums are balanced
+                // binary trees over the 16-channel tiles, so the result does not depend on how many waves share a row
+                // (the 4- and 8-wave variants of one C must agree bit for bit: batch-size independence).
+                float mean[TMW], rstd[TMW];
+#pragma unroll
+                for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                    for (int j = 0; j < TMW; ++j) {
+                        float part[TNW];
+#pragma unroll
+                        for (int i = 0; i < TNW; ++i) {
+                            if (pass == 0) part[i] = (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                            else {
+                                const f32x4 d = acc[i][j] - mean[j];
+                                part[i] = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+                            }
+                            part[i] = red_xor32<RedSum>(red_xor16<RedSum>(part[i]));   // the tile's 16 channels
+                        }
+                        const float sacc = tree_sum<TNW>(part);
+                        if (fg == 0) Red[(pass * WAVES + wave) * 64 + (wm * TMW + j) * 16 + fr] = sacc;
+                    }
+                    lds_barrier();
+#pragma unroll
+                    for (int j = 0; j < TMW; ++j) {
+                        float wsum[WN];
+#pragma unroll
+                        for (int w2 = 0; w2 < WN; ++w2) wsum[w2] = Red[(pass * WAVES + wm * WN + w2) * 64 + (wm * TMW + j) * 16 + fr];
+                        const float tot = tree_sum<WN>(wsum);
+                        if (pass == 0) mean[j] = tot * (1.0f / C);
+                        else rstd[j] = 1.0f / sqrtf(tot * (1.0f / C) + 1e-5f);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TNW; ++i) {
+                    const int n = (wn * TNW + i) * 16 + fg * 4;
+                    const f32x4 g2 = *reinterpret_cast<const f32x4*>(p.gamma2 + n), b2 = *reinterpret_cast<const f32x4*>(p.beta2 + n);
+#pragma unroll
+                    for (int j = 0; j < TMW; ++j)
+                        store4(reinterpret_cast<T*>(Xn + ((wm * TMW + j) * 16 + fr) * SA) + n, (acc[i][j] - mean[j]) * rstd[j] * g2 + b2);
+                }
+            }
+        }
+    }
+    if constexpr (SZ == 2) {
+        if (p.h1) {
+            lds_barrier();
+            fc1_units<T, C, WAVES>(Xn, SA, reinterpret_cast<const T*>(p.W1), p.b1, reinterpret_cast<T*>(p.h1), m0, p.H, p.W, p.shift, wave, lane);
         }
     }
     census.end(p.tbuf, bw);
@@ -358,7 +502,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 
 template <typename T, int C, int NT>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
-    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4;
+    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT>;
     static bool attr_done = false;
@@ -371,10 +515,12 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
         attr_done = true;
     }
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "attn_block_%s_c%d_nt%d %dx%d", sizeof(T) == 2 ? "bf16" : "f32", C, NT, p.n_windows * 64, C);
+    if (timing_enabled())
+        snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", p.h1 ? "_fc1" : "", sizeof(T) == 2 ? "bf16" : "f32", C, NT, p.n_windows * 64, C);
     const double M = (double)p.n_windows * 64;
+    const double fc1_flops = p.h1 ? 2.0 * M * C * 4.0 * C : 0.0, fc1_bytes = p.h1 ? M * 4.0 * C * sizeof(T) + 4.0 * C * C * sizeof(T) : 0.0;
     {
-        ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0), M * C * 8.0 + 4.0 * C * C * sizeof(T), st);
+        ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0) + fc1_flops, M * C * 8.0 + 4.0 * C * C * sizeof(T) + fc1_bytes, st);
         hipLaunchKernelGGL(kern, dim3(p.n_windows), dim3(NT), smem, st, p);
     }
     return check_launch("attn_block");
@@ -396,11 +542,13 @@ bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_
     return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
 }
 
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, hipStream_t st) {
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st) {
     AttnBlkParams p{};
     p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
     p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;
+    p.gamma2 = bp->norm2_w; p.beta2 = bp->norm2_b; p.W1 = bp->w1_fm; p.b1 = bp->b1;
+    p.h1 = dtype == UF_BF16 ? h1_out : nullptr;   // phase 3 exists for 2-byte operands only
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = g_tbuf;

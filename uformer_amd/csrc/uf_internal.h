@@ -34,6 +34,7 @@ int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStre
 // fused attention half (uf_attnblk.hip)
 void debug_set_tbuf(void* p);
 bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads);
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, hipStream_t st);
+// h1_out != NULL (and dtype bf16): the kernel also writes h1 = GELU(linear1(LN2(x_new))), T[B*H*W][4C]
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st);
 
 }  // namespace uf

@@ -47,15 +47,21 @@ int check_block_args(const uf_block_params* p, const float* x, int ld, int B, in
     return UF_OK;
 }
 
+// fc1_done (optional): set when the fused kernel also produced the LeFF hidden h1 in w.h1 (whole-block calls only)
 int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask,
-              uf_dtype dtype, const BlockWs& w, hipStream_t st) {
+              uf_dtype dtype, const BlockWs& w, hipStream_t st, bool* fc1_done = nullptr) {
     const int M = B * H * W;
     const size_t sz = dtype_size(dtype);
     const int heads = p->heads, hd = C / heads;
     // one fused kernel per window when the shape is covered (head_dim 32): LN1, q/k/v, attention, proj,
     // window_reverse and the residual never leave the CU                       (model.py:951-986)
     static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
-    if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) return launch_attn_block(p, x, ld, B, H, W, C, dtype, st);
+    static const bool no_fc1 = getenv("UF_NO_FC1_FUSION") != nullptr;
+    if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) {
+        const bool with_fc1 = fc1_done && !no_fc1 && dtype == UF_BF16 && C >= 32;
+        if (fc1_done) *fc1_done = with_fc1;
+        return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st);
+    }
     // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
     // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
@@ -76,11 +82,13 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 }
 
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
-              hipStream_t st) {
+              hipStream_t st, bool fc1_done = false) {
     const int M = B * H * W;
-    // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671)
-    int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1_fm, p->b1, w.h1, M, 4 * C, C, dtype, st);
-    if (rc) return rc;
+    // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671) unless the attention kernel did it
+    if (!fc1_done) {
+        int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1_fm, p->b1, w.h1, M, 4 * C, C, dtype, st);
+        if (rc) return rc;
+    }
     // depthwise 3x3 + GELU over the whole H x W map, linear2, + residual: one kernel, the conv output
     // stays on chip                                      (model.py:659-661, :674-682, :987)
     return uf_dwconv_linear2_fwd(w.h1, p->wdw9, p->bdw, p->w2_fm, p->b2, x, ld, B, H, W, C, dtype, st);
@@ -123,9 +131,10 @@ extern "C" int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, in
     BlockWs w;
     rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
     if (rc) return rc;
-    rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream);
+    bool fc1_done = false;
+    rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream, &fc1_done);
     if (rc) return rc;
-    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream);
+    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream, fc1_done);
 }
 
 extern "C" int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B,
