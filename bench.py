@@ -157,6 +157,16 @@ def main():
             ach = dom["bytes"] / sec / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        # HBM bytes per launch of that kernel from the committed PMC passes of this same workload (None if never profiled)
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+                tr = json.load(f)["kernels"].get(name)
+            if tr:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = ("bytes per launch, FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_traffic.json; "
+                                                   f"algorithmic bytes per launch {dom['bytes'] / dom['launches']:.4g}")
+        except (OSError, ValueError, KeyError):
+            pass
         out["roofline"]["flop_per_byte"] = dom["flops"] / max(dom["bytes"], 1.0)
         out["roofline"]["achieved_tflops"] = dom["flops"] / sec / 1e12
         out["roofline"].update({"kernel": name, "launches_per_step": dom["launches"] // 3,

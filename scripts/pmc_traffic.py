@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch of every library kernel, from the FETCH_SIZE / WRITE_SIZE PMC passes
+(scripts/pmc_passes.sh -> <dir>/pmcC_pmc.csv, <dir>/pmcD_pmc.csv), keyed by the library's timing symbol so
+bench.py can attach it to `roofline.traffic`.
+
+    python scripts/pmc_traffic.py gpurun_out profiles/r01_pmc_traffic.json
+
+Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE counts
+128-B requests of wide (16 B/lane) streaming reads as 64 B, so it is DOUBLED here -- every hot read in these kernels
+is a 16-B/lane load.  WRITE_SIZE is taken as reported (uncalibrated in the guide)."""
+import collections
+import csv
+import json
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+
+
+def symbol(kernel):
+    m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)>", kernel)
+    if m:
+        return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
+    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+)>", kernel)
+    if m:
+        return f"leff2_bf16_c{m.group(1)}_np{m.group(2)}"
+    m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)>", kernel)
+    if m:
+        return f"gemm_bf16_bn{m.group(1)}_a{m.group(2)}_e{m.group(3)}"
+    if "input_proj_kernel" in kernel:
+        return "input_proj"
+    if "output_proj_kernel" in kernel:
+        return "output_proj"
+    return None
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        s = symbol(r["kernel"])
+        if s:
+            n = int(r["dispatches"])
+            acc[s][0] += float(r[counter]) * 1024.0 * n
+            acc[s][1] += n
+    return {s: (b / n, n) for s, (b, n) in acc.items()}
+
+
+fetch, write = load(f"{src}/pmcC_pmc.csv", "FETCH_SIZE"), load(f"{src}/pmcD_pmc.csv", "WRITE_SIZE")
+out = {}
+for s in sorted(fetch):
+    f, n = fetch[s]
+    w = write.get(s, (0.0, 0))[0]
+    out[s] = {"fetch_bytes_per_launch": 2.0 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2.0 * f + w, "dispatches_profiled": n}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1; "
+                     "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; average over the launches of a symbol",
+           "kernels": out}, open(dst, "w"), indent=1)
+for s, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    print(f"{s:40s} fetch {v['fetch_bytes_per_launch'] / 1e6:8.1f} MB  write {v['write_bytes_per_launch'] / 1e6:8.1f} MB  (n={v['dispatches_profiled']})")
