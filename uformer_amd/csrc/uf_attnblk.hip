@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;   // fragment-major tiles
         // weight fragments come from L2 (>= 500 cycles): ring of WR k-steps in flight where registers allow; the
         // activation fragments come from LDS, one step ahead is enough
-        constexpr int WR = (SZ == 2 && C >= 128 && C <= 256) ? 3 : 2;
+        constexpr int WR = (SZ == 2 && C >= 128) ? 3 : 2;
         Frag<T> wf[WR][6], af[2][4];
         Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
         auto wload = [&](int ks, int slot) {
@@ -411,7 +411,8 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         for (int i = 0; i < TNW; ++i)
 #pragma unroll
             for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        Frag<T> wf[2][TNW], af[2][TMW];
+        constexpr int PR = SZ == 2 ? 3 : 2;   // weight ring depth (k-steps in flight)
+        Frag<T> wf[PR][TNW], af[2][TMW];
         auto wload = [&](int ks, int slot) {
 #pragma unroll
             for (int i = 0; i < TNW; ++i) load_frag(wf[slot][i], Wp + (((size_t)(wn * TNW + i) * KS + ks) * 64 + lane) * 8);
@@ -420,16 +421,19 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 #pragma unroll
             for (int j = 0; j < TMW; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Os + ((wm * TMW + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
         };
-        wload(0, 0);
+#pragma unroll
+        for (int pf = 0; pf < PR - 1; ++pf)
+            if (pf < KS) wload(pf, pf);
         aload(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) { wload(ks + 1, (ks + 1) & 1); aload(ks + 1, (ks + 1) & 1); }
+            if (ks + PR - 1 < KS) wload(ks + PR - 1, (ks + PR - 1) % PR);
+            if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TNW; ++i)
 #pragma unroll
-                for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks & 1][i], af[ks & 1][j]);
+                for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks % PR][i], af[ks & 1][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(7);
