@@ -52,7 +52,9 @@ int uf_last_error(char* buf, size_t n);
  * returns the length the full text needs.  bench.py uses it for the live roofline figure. */
 int uf_timing_enable(int on);
 int uf_timing_report(char* json, size_t n);
-/* development aid: device buffer (u64) that instrumented kernels fill with cycle-counter stamps; NULL = off */
+/* development aid: device buffer of u64 that instrumented kernels fill -- sampled phase stamps in entries [0, 65536),
+ * then one 8-entry census record per workgroup {s_memtime start, end, 100 MHz clock start, end, HW_ID|XCC_ID<<32}: the
+ * buffer must hold 65536 + 8 * (largest grid) entries.  NULL = off (the default). */
 int uf_debug_set_tbuf(void* p);
 
 /* ---- fragment-major weights ------------------------------------------------------------------

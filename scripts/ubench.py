@@ -7,6 +7,10 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+# uf_debug_set_tbuf buffer: sampled phase stamps in the first 65536 entries, then the per-workgroup census
+# (8 entries per workgroup, uf_common.h struct Census) for up to 32768 workgroups
+TBUF_ELEMS = 65536 + 8 * 32768
+
 from uformer_amd import ops
 
 
@@ -80,7 +84,7 @@ def bench_stamps():
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         waves = 8 if C == 512 else 4
-        tb = torch.zeros((M // 64 // 64 + 1) * waves * 16, dtype=torch.int64, device="cuda")
+        tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
         for _ in range(3):
             lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
@@ -88,7 +92,7 @@ def bench_stamps():
         lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(None)
-        t = tb.cpu().reshape(-1, waves, 16)
+        t = tb[:65536].cpu().reshape(-1, waves, 16)
         t0 = t[..., 0].min()
         print(f"C={C}: stamps relative to first block start, wave 0 of sampled blocks (cycles @100MHz? raw counter units)")
         for bi in range(min(t.shape[0], 6)):
@@ -113,7 +117,7 @@ def bench_stamps_leff2():
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         nblk = M // 64
-        tb = torch.zeros((nblk // 64 + 1) * 16 * 4, dtype=torch.int64, device="cuda")
+        tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
         for _ in range(3):
             lib.uf_leff_fwd(bp, x.data_ptr(), C, B, H, H, C, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
@@ -121,7 +125,7 @@ def bench_stamps_leff2():
         lib.uf_leff_fwd(bp, x.data_ptr(), C, B, H, H, C, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(None)
-        t = tb.cpu().reshape(-1, 16, 4).float()[:4]
+        t = tb[:65536].cpu().reshape(-1, 16, 4).float()[:4]
         n = 4 * C // 64 + 1
         act = t[..., 0] > 0
         pr = act & (t[..., 2] > 0)
@@ -145,13 +149,13 @@ def bench_stamps_lngemm():
         b1 = torch.zeros(4 * C, device="cuda")
         for _ in range(3):
             ops.ln_linear_gelu(x, g, b, w1, b1)
-        tb = torch.zeros((M // 64 // 64 + 2) * 4 * 4, dtype=torch.int64, device="cuda")
+        tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(tb.data_ptr())
         ops.ln_linear_gelu(x, g, b, w1, b1)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(None)
-        t = tb.cpu().reshape(-1, 4, 4).float()
+        t = tb[:65536].cpu().reshape(-1, 4, 4).float()
         t = t[t[:, 0, 3] > 0][:4]
         nu = t[:, :, 3].mean()
         print(f"ln_fc1 M={M} C={C}: per wave (cycles): LN phase {t[:, :, 0].mean():.0f} | k-loops total {t[:, :, 1].mean():.0f} epilogues total {t[:, :, 2].mean():.0f} "
@@ -203,7 +207,7 @@ def bench_census():
         b2 = torch.zeros(C, device="cuda")
         wd = torch.randn(9, 4 * C, device="cuda") * 0.2
         bd = torch.zeros(4 * C, device="cuda")
-        tb = torch.zeros(65536 + 8 * 8192, dtype=torch.int64, device="cuda")
+        tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
         for _ in range(2):
             h1 = ops.ln_linear_gelu(x, g, b, w1, b1)
         torch.cuda.synchronize()
