@@ -47,13 +47,14 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-// Wave-specialised version.  512 threads = 8 waves; the hardware places waves w and w+4 of a workgroup
-// on the same SIMD, so every SIMD hosts one PRODUCER wave (0-3: depthwise stencil + GELU, pure VALU/LDS)
-// and one CONSUMER wave (4-7: halo + tap + W2 traffic, MFMAs, epilogue).  The VALU and matrix pipes of a
-// SIMD run concurrently for two different waves, so the stencil of chunk i overlaps the MFMAs of chunk
-// i-1; halo tile, tap table and operand tile are double-buffered in LDS, one barrier per chunk.
-template <typename T, int C, int NP>
-__global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(const Leff2Params p) {
+// Wave-specialised version.  NP + NC waves; the hardware places waves w, w+4, w+8 of a workgroup on the same
+// SIMD, so every SIMD hosts one PRODUCER wave (0..NP-1: depthwise stencil + GELU, pure VALU/LDS) and NC/4 CONSUMER
+// waves (halo + tap + W2 traffic, MFMAs, epilogue; NC = 4, or 8 where the accumulators of C >= 256 output channels
+// would otherwise make the consumers the long pole).  The VALU and matrix pipes of a SIMD run concurrently for
+// different waves, so the stencil of chunk i overlaps the MFMAs of chunk i-1; halo tile, tap table and operand tile
+// are double-buffered in LDS, one barrier per chunk.
+template <typename T, int C, int NP, int NC>
+__global__ __launch_bounds__((NP + NC) * 64, (NP + NC) / 4) void leff2_kernel(const Leff2Params p) {
     constexpr int SR = 8 / NP;                    // rows of the column strip one producer thread convolves (NP = 4 or 8 producer waves)
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
@@ -63,8 +64,10 @@ __global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(cons
     constexpr int SH = KC * SZ + 16;              // LDS row stride, halo tile [HT][KC]
     constexpr int SAT = KC * SZ + 16;             // LDS row stride, operand tile [BM][KC]
     constexpr int CPP = KC * SZ / 16;             // 16-byte pieces per pixel per chunk
-    constexpr int NLD = (HT * CPP + 255) / 256;   // staged 16-byte loads per consumer thread
-    constexpr int WN = (C / 16) < 4 ? (C / 16) : 4, WM = 4 / WN;   // consumer wave grid (pixels x out channels)
+    constexpr int NCT = NC * 64;                  // consumer threads
+    constexpr int NLD = (HT * CPP + NCT - 1) / NCT;   // staged 16-byte loads per consumer thread
+    constexpr int WN = (C / 16) < NC ? (C / 16) : NC, WM = NC / WN;   // consumer wave grid (pixels x out channels)
+    static_assert(WM <= 4 && NC * 64 >= 160, "consumer grid");
     constexpr int TMW = 4 / WM, TNW = (C / 16) / WN;               // 16x16 tiles per consumer wave
     constexpr int HS_BYTES = HT * SH, AT_BYTES = BM * SAT, WL_BYTES = 10 * KC * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,7 +152,7 @@ __global__ __launch_bounds__((NP + 4) * 64, (NP + 4) / 4) void leff2_kernel(cons
     int s_lds[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int idx = ct + 256 * i;
+        const int idx = ct + NCT * i;
         const int hp = idx / CPP, piece = idx - hp * CPP;
         const int hy = hp / HW_, hx = hp - hy * HW_;
         const int iy = y0 + hy - 1, ix = x0 + hx - 1;
@@ -249,9 +252,11 @@ template <typename T, int C>
 int launch_c(const Leff2Params& p, hipStream_t st) {
     constexpr int SZ = sizeof(T);
     // one producer (stencil) wave + one consumer (MFMA) wave per SIMD
-    constexpr int NP = 4;
+    // one producer (stencil) wave per SIMD; C >= 256 cannot fit two workgroups per CU anyway (accumulators), so it gets
+    // 8 consumer waves (half the accumulators, W2 fragments and MFMAs per wave): the consumers stop being the long pole
+    constexpr int NP = 4, NC = (SZ == 2 && C >= 256) ? 8 : 4;
     constexpr int smem = 2 * 100 * (KC * SZ + 16) + 2 * 64 * (KC * SZ + 16) + 2 * 10 * KC * 4;
-    auto kern = leff2_kernel<T, C, NP>;
+    auto kern = leff2_kernel<T, C, NP, NC>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -263,10 +268,10 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
     }
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, NP, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, NP, NC, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((NP + 4) * 64), smem, st, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((NP + NC) * 64), smem, st, p);
     }
     return check_launch("leff2");
 }
