@@ -21,9 +21,9 @@ def symbol(kernel):
     m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)>", kernel)
     if m:
         return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
-    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+)>", kernel)
+    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+)>", kernel)
     if m:
-        return f"leff2_bf16_c{m.group(1)}_np{m.group(2)}"
+        return f"leff2_bf16_c{m.group(1)}_np{m.group(2)}_nc{m.group(3)}"
     m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)>", kernel)
     if m:
         return f"gemm_bf16_bn{m.group(1)}_a{m.group(2)}_e{m.group(3)}"
@@ -45,7 +45,13 @@ def load(path, counter):
     return {s: (b / n, n) for s, (b, n) in acc.items()}
 
 
-fetch, write = load(f"{src}/pmcC_pmc.csv", "FETCH_SIZE"), load(f"{src}/pmcD_pmc.csv", "WRITE_SIZE")
+import os
+def first(*names):
+    for n in names:
+        if os.path.exists(f"{src}/{n}"):
+            return f"{src}/{n}"
+    raise SystemExit(f"none of {names} under {src}")
+fetch, write = load(first("pmcC_pmc.csv", "r01_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r01_final_pmcD.csv"), "WRITE_SIZE")
 out = {}
 for s in sorted(fetch):
     f, n = fetch[s]
