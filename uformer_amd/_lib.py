@@ -10,6 +10,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libuformer_hip.so")
+# A/B builds and out-of-tree installs: UFORMER_HIP_LIB=/path/to/libuformer_hip.so overrides the in-tree library
+LIB_PATH = os.environ.get("UFORMER_HIP_LIB", LIB_PATH)
 
 UF_F32, UF_BF16 = 0, 1
 

@@ -54,7 +54,10 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
 // different waves, so the stencil of chunk i overlaps the MFMAs of chunk i-1; halo tile, tap table and operand tile
 // are double-buffered in LDS, one barrier per chunk.
 template <typename T, int C, int NP, int NC>
-__global__ __launch_bounds__((NP + NC) * 64, (NP + NC) / 4) void leff2_kernel(const Leff2Params p) {
+// C <= 64: cap registers at 85 (6 waves per SIMD) so THREE workgroups fit a CU (LDS allows it: 3 x 52 KiB); the few chunks
+// per tile at small C make pipeline fill/drain a third of a workgroup's life, and a third resident workgroup hides it
+// (A/B on one box: 369 -> 308 us at C=64, 1 M tokens).  C = 128 spills under that cap and stays at two.
+__global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void leff2_kernel(const Leff2Params p) {
     constexpr int SR = 8 / NP;                    // rows of the column strip one producer thread convolves (NP = 4 or 8 producer waves)
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
