@@ -213,7 +213,10 @@ typedef struct uf_model_desc {
 } uf_model_desc;
 
 size_t uf_uformer_workspace_bytes(const uf_model_desc* d, int B, int H, int W, uf_dtype dtype);
-/* img, out: f32 NCHW (B,dd_in,H,W) / (B,in_chans,H,W).  H == W, multiple of 128. */
+/* img, out: f32 NCHW (B,dd_in,H,W) / (B,in_chans,H,W).  H == W, multiple of 128.
+ * All work is ordered on `stream`: for B >= 8 the library cuts the batch in two and runs the second half on an
+ * internal side stream forked from / joined back into `stream` with events (kernel ramps and tails of the halves
+ * overlap; results are bit-identical); UF_STREAMS=1 in the environment turns that off, UF_STREAMS=n (<= 8) forces n. */
 int uf_uformer_fwd(const uf_model_desc* d, const float* img, float* out, int B, int H, int W,
                    uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 
