@@ -27,6 +27,8 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (same guide)
 GFLOP_PER_IMAGE_B256 = 173.15   # 2 x 86.574 GMAC, Uformer-B @256x256
+MB_PER_IMAGE_B256 = 184.8       # same section: compulsory bf16 activation bytes per image (blocks in+out once, samplers, skips, stem/head)
+MB_WEIGHTS_B = 101.8            # bf16 weights, read once per batch
 
 
 def kernel_breakdown(model, x, steps):
@@ -136,6 +138,9 @@ def main():
             "model_gflop_per_image": flops_img / 1e9,
             "mfma_frac_whole_model": value * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype],
         }
+        if args.arch == "Uformer_B" and args.img == 256 and args.dtype == "bf16":
+            # SURVEY 8d "report both fractions": compulsory (ideal whole-block fusion) HBM bytes vs the 8 TB/s peak
+            out["hbm_frac_whole_model_compulsory"] = value * (MB_PER_IMAGE_B256 + MB_WEIGHTS_B / args.batch) * 1e6 / world / (HBM_PEAK_GBS * 1e9)
         # ---- roofline of the dominant kernel: HIP events on the launch stream, per kernel class ----
         rows = kernel_breakdown(model, x, 3)
         total_ms = sum(r["ms"] for r in rows)

@@ -61,9 +61,7 @@ int uf_debug_set_tbuf(void* p);
  * The fused kernels stream nn.Linear weights W[N][K] straight from L2 into MFMA operand registers.
  * They take W re-laid out so that one wave-level load is 1 KiB contiguous:
  *     out[((n/16 * KS + k/32) * 64 + ((k%32)/8)*16 + n%16) * 8 + k%8] = W[n][k],   KS = ceil(K/32),
- * zero padded in k.  Arguments named *_fm below are in this layout (uf_weight_fm_elems elements).
- * The relative-position bias has the analogous layout rpb_fm[h][qt][kt][lane][4] =
- * bias[h][16qt + lane%16][16kt + 4(lane/16) + 0..3]. */
+ * zero padded in k.  Arguments named *_fm below are in this layout (uf_weight_fm_elems elements). */
 size_t uf_weight_fm_elems(int N, int K);
 int uf_pack_weight_fm(const void* w_rowmajor, void* out_fm, int N, int K, uf_dtype dtype, void* stream);
 
@@ -140,9 +138,9 @@ typedef struct uf_block_params {
     const float* norm1_b;   /* norm1.bias */
     const float* modulator; /* modulator.weight (64,C) or NULL */
     const float* rpb_dense; /* (heads,64,64) gathered from attn.relative_position_bias_table */
-    const float* rpb_fm;    /* the same values, fragment-major (heads,4,4,64,4) */
+    const float* rpb_fm;    /* reserved (was a fragment-major copy of rpb_dense); ignored, may be NULL */
     const float* rpb_tab;   /* (heads,15,15) compact table [dy+7][7-dx] when the bias is Toeplitz (always, for the
-                               reference's relative_position_index), else NULL -> kernels use rpb_fm */
+                               reference's relative_position_index), else NULL -> the 3-kernel path with rpb_dense */
     const void* wqkv_fm;    /* T (3C,C) fragment-major: attn.qkv.to_q.weight ; attn.qkv.to_kv.weight */
     const float* bqkv;      /* (3C) */
     const void* wproj;      /* T (C,C) attn.proj.weight, row-major (3-kernel fallback path) */

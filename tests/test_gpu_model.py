@@ -180,3 +180,18 @@ def test_hires_720p_padded_to_1280(model_b):
     ps = O.psnr(crop(yb), crop(yf))
     REPORT["B_720p_bf16_vs_f32"] = {"max_abs_err": (crop(yb) - crop(yf)).abs().max().item(), "psnr_db": ps}
     assert ps >= BF16_PSNR
+
+
+def test_restore_wrapper_rectangular():
+    """uformer_amd.infer.restore (pad -> forward -> crop -> clamp, test/test_sidd.py:106-109) on a 72x200 image against
+    the same steps through the oracle."""
+    from uformer_amd import infer
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 5)
+    m = build(cfg, sd, torch.float32)
+    img = spec.synth_input(1, 72, 200, 11)
+    got = infer.restore(m, img.cuda()).cpu()
+    xp, msk = O.expand2square(img, 128.0)
+    ref = O.uformer_forward(xp, sd, img_size=128, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads)
+    exp = torch.clamp(torch.masked_select(ref, msk.bool()).reshape(1, 3, 72, 200), 0, 1)
+    compare("restore_72x200_f32", got, exp, torch.float32)

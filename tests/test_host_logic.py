@@ -89,3 +89,20 @@ def test_shard_batch():
         assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
         sizes = [b - a for a, b in parts]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_infer_wrapper_matches_reference_padding():
+    """uformer_amd.infer.expand2square / crop_to_mask == the reference helper (test/test_sidd.py:79-92) restated in the
+    oracle, including the masked_select crop, for odd sizes; restore() = pad -> model -> crop -> clamp."""
+    import torch
+    from oracle import uformer_oracle as O
+    from uformer_amd import infer
+    for (h, w) in ((200, 136), (72, 128), (128, 128), (130, 250)):
+        img = torch.rand(1, 3, h, w)
+        a, ma = infer.expand2square(img, 128.0)
+        b, mb = O.expand2square(img, 128.0)
+        assert torch.equal(a, b) and torch.equal(ma, mb)
+        crop = torch.masked_select(a, ma.bool()).reshape(1, 3, h, w)
+        assert torch.equal(infer.crop_to_mask(a, h, w), crop) and torch.equal(crop, img)
+    out = infer.restore(lambda x: x * 2.0 - 0.25, torch.rand(2, 3, 40, 24), factor=16.0)
+    assert out.shape == (2, 3, 40, 24) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0

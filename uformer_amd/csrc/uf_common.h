@@ -32,22 +32,9 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 // exact erf GELU (nn.GELU default; reference model.py:657-660)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-// erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution): ~16 VALU ops with
-// v_rcp_f32 / v_exp_f32 instead of erff's ~35 with branches.  Used wherever the result is stored as
-// bf16; the f32 (parity) mode keeps erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = 1.0f - poly * t * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
 // GELU for results that are STORED AS bf16: x * sigmoid(2*sqrt(2/pi)*(x + 0.044715 x^3)) = x / (1 + 2^(x*(A + B*x^2))),
 // two values per call so the plain ops become v_pk_mul/v_pk_fma_f32 (6 packed-pair VALU + 2x(v_exp,v_rcp) instead of
-// 2x(14 VALU + 2 transcendental) for the A-S erf above).  |tanh form - erf form| <= 4.8e-4 (at |x| ~ 2.7, where bf16's
+// 2x(14 VALU + 2 transcendental) for an Abramowitz-Stegun erf, ~35 with branches for erff).  |tanh form - erf form| <= 4.8e-4 (at |x| ~ 2.7, where bf16's
 // half-ulp is 7.8e-3): 16x under the storage rounding; the whole Uformer-B output moves by 5.8e-5 (95.9 dB), measured
 // on the oracle, against 2e-3 / 67 dB for bf16 operands themselves.  The f32 (parity) mode never uses it.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -58,8 +45,6 @@ __device__ __forceinline__ f32x2_t gelu_bf2(f32x2_t x) {
     const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 }
-template <typename T> __device__ __forceinline__ float gelu_t(float x) { return gelu_erf(x); }
-template <> __device__ __forceinline__ float gelu_t<bf16>(float x) { return gelu_fast(x); }
 // in-place GELU of N (even) values in the flavour the operand type T calls for
 template <typename T, int N> __device__ __forceinline__ void gelu_n(float* v) {
     if constexpr (sizeof(T) == 2) {

@@ -33,12 +33,6 @@ def pack_frag(w: Tensor, dtype: torch.dtype) -> Tensor:
     return w.reshape(N // 16, 16, KP // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous()
 
 
-def pack_rpb_frag(dense: Tensor) -> Tensor:
-    """(heads,64,64) bias -> (heads,4,4,64,4): [h][qt][kt][lane = fg*16+fr][r] = bias[h][16qt+fr][16kt+4fg+r]."""
-    h = dense.shape[0]
-    return dense.reshape(h, 4, 16, 4, 4, 4).permute(0, 1, 3, 4, 2, 5).contiguous().float()
-
-
 def pack_rpb_table(dense: Tensor):
     """(heads,64,64) bias -> compact (heads,15,15) table T[h][dy+7][7-dx] with dy = yq-yk, dx = xq-xk, if the bias is
     Toeplitz in (dy,dx) (true for the reference's relative_position_index, model.py:467-477); else None."""
@@ -88,7 +82,7 @@ def pack_block(sd: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype
     dense = rpb_dense(sd[prefix + "attn.relative_position_bias_table"], sd[prefix + "attn.relative_position_index"])
     keep: Dict[str, Tensor] = {
         "norm1_w": f("norm1.weight"), "norm1_b": f("norm1.bias"),
-        "rpb_dense": dense, "rpb_fm": pack_rpb_frag(dense),
+        "rpb_dense": dense,
         "wqkv_fm": pack_frag(wqkv, dtype),
         "bqkv": torch.cat([sd[prefix + "attn.qkv.to_q.bias"].detach(), sd[prefix + "attn.qkv.to_kv.bias"].detach()], 0).contiguous().float(),
         "wproj": t("attn.proj.weight"), "wproj_fm": pack_frag(sd[prefix + "attn.proj.weight"], dtype), "bproj": f("attn.proj.bias"),
