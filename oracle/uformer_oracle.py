@@ -300,6 +300,13 @@ def expand2square(img: Tensor, factor: float = 128.0):
     return out, msk
 
 
+def charbonnier_loss(x: Tensor, y: Tensor, eps: float = 1e-3) -> Tensor:
+    """CharbonnierLoss.forward: mean(sqrt((x-y)^2 + eps^2)).  losses.py:41-52 (training criterion,
+    train/train_denoise.py:164,181)."""
+    d = x - y
+    return torch.mean(torch.sqrt(d * d + eps * eps))
+
+
 def psnr(a: Tensor, b: Tensor) -> float:
     """myPSNR: 20*log10(1/rmse) on clamped tensors.  utils/image_utils.py:40-44."""
     d = torch.clamp(a, 0, 1) - torch.clamp(b, 0, 1)

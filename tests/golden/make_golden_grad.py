@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Golden GRADIENT fixtures, generated FROM THE REFERENCE ITSELF with torch autograd.
+
+Runs only in the build container (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_grad.py
+
+Same harness as make_golden.py (reference model.py imported unmodified behind the 3-symbol timm shim).  Modules are in
+eval() mode, so DropPath is the identity and the gradients are deterministic; the loss of the whole-model fixture is the
+reference's CharbonnierLoss (losses.py:41-52, eps 1e-3) against a seeded target, as in train/train_denoise.py:180-184.
+These fixtures pin the backward of oracle/uformer_oracle.py (tests/test_oracle_golden.py) before any backward kernel
+exists; they are the ground truth the round-2 backward kernels will be held to.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (installs the shim, imports the reference as mg.ref)
+
+ref, spec, g, save = mg.ref, mg.spec, mg.g, mg.save
+sys.path.insert(0, mg.REF)
+import losses as ref_losses  # noqa: E402  (reference losses.py: torch only)
+
+
+def main():
+    torch.set_num_threads(8)
+    # ---------------- one LeWin block: shifted windows, 2 heads, modulator ---------------------------------
+    C, heads = 64, 2
+    blk = ref.LeWinTransformerBlock(C, (16, 16), heads, win_size=8, shift_size=4, token_mlp="leff", modulator=True).eval()
+    mg.randomize_(blk, 131)
+    x = torch.randn(2, 256, C, generator=g(132), requires_grad=True)
+    gy = torch.randn(2, 256, C, generator=g(133))
+    y = blk(x)
+    y.backward(gy)
+    save("grad_lewin_block", heads=heads, x=x.detach(), gy=gy, y=y.detach(), dx=x.grad,
+         **{"p." + k: v for k, v in blk.state_dict().items()},
+         **{"g." + k: p_.grad for k, p_ in blk.named_parameters()})
+
+    # ---------------- whole tiny32 model, Charbonnier loss ---------------------------------------------------
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 1234)
+    m = ref.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+                    win_size=8, token_projection="linear", token_mlp="leff", modulator=cfg.modulator, dd_in=cfg.dd_in).eval()
+    m.load_state_dict(sd, strict=True)
+    xin = spec.synth_input(1, 128, 128, 1234).requires_grad_(True)
+    target = spec.synth_input(1, 128, 128, 1235)
+    loss = ref_losses.CharbonnierLoss()(m(xin), target)
+    loss.backward()
+    names = [k for k, _ in m.named_parameters()]
+    stats = np.stack([[float(p_.grad.sum()), float(p_.grad.abs().sum()), float(p_.grad.abs().max())] for _, p_ in m.named_parameters()])
+    full = {}
+    for k, p_ in m.named_parameters():   # a representative of every parameter kind, stored in full
+        if k in ("input_proj.proj.0.weight", "output_proj.proj.0.weight", "dowsample_0.conv.0.weight", "upsample_3.deconv.0.weight",
+                 "encoderlayer_0.blocks.0.attn.qkv.to_q.weight", "encoderlayer_0.blocks.0.attn.relative_position_bias_table",
+                 "encoderlayer_0.blocks.0.norm1.weight", "conv.blocks.0.mlp.dwconv.0.weight", "conv.blocks.0.mlp.linear1.0.bias",
+                 "decoderlayer_3.blocks.0.modulator.weight", "decoderlayer_3.blocks.0.attn.qkv.to_kv.weight",
+                 "decoderlayer_3.blocks.0.mlp.linear2.0.weight"):
+            full["g." + k] = p_.grad
+    assert len(full) == 12, sorted(full)
+    save("grad_model_tiny32_128", loss=loss.detach(), dx=xin.grad, param_names=np.array(names), grad_stats=stats, **full)
+    print("loss %.6f  |dx| max %.3e  params %d" % (float(loss), float(xin.grad.abs().max()), len(names)))
+
+
+if __name__ == "__main__":
+    main()

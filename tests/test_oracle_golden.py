@@ -112,3 +112,53 @@ def test_block_shifts_ctor_clamp():
     assert spec.arch_config("Uformer_B", 128).block_shifts()[4] == [0, 0]
     assert O.block_shifts(128, (1, 2, 8, 8, 2, 8, 8, 2, 1))[4] == [0, 0]
     assert len(spec.state_dict_spec(spec.arch_config("Uformer_B"))) == 759
+
+
+# ---- backward: the oracle is a functional torch restatement, so torch autograd differentiates it;
+# these tests hold THAT backward to gradients produced by the reference's own autograd (tests/golden/make_golden_grad.py)
+# -- the ground truth for the backward kernels of the next round.
+GRAD_RTOL = 2e-4
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(1e-12, b.abs().max().item())
+
+
+def test_lewin_block_backward(golden):
+    g = golden("grad_lewin_block")
+    p = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in params(g, "p.").items()}
+    x = t(g["x"]).clone().requires_grad_(True)
+    y = O.lewin_block(x, p, "", int(g["heads"]), 4)
+    assert (y - t(g["y"])).abs().max() < TOL
+    y.backward(t(g["gy"]))
+    assert _rel(x.grad, t(g["dx"])) < GRAD_RTOL
+    grads = params(g, "g.")
+    assert len(grads) == 18      # every parameter of the block (the int64 index buffer has no gradient)
+    for k, ref in grads.items():
+        assert p[k].grad is not None, k
+        assert _rel(p[k].grad, ref) < GRAD_RTOL, (k, _rel(p[k].grad, ref))
+
+
+def test_model_backward_charbonnier(golden):
+    g = golden("grad_model_tiny32_128")
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(1, 128, 128, 1234).requires_grad_(True)
+    target = spec.synth_input(1, 128, 128, 1235)
+    y = O.uformer_forward(x, sd, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    loss = O.charbonnier_loss(y, target)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    loss.backward()
+    assert _rel(x.grad, t(g["dx"])) < GRAD_RTOL
+    names = [str(n) for n in g["param_names"]]
+    stats = g["grad_stats"]
+    assert names == [k for k, v in sd.items() if v.is_floating_point()]       # parameter order == reference named_parameters()
+    for n, (s_sum, s_abs, s_max) in zip(names, stats):
+        gr = sd[n].grad
+        assert gr is not None, n
+        assert abs(gr.abs().sum().item() - s_abs) <= 5e-4 * s_abs + 1e-9, n
+        assert abs(gr.abs().max().item() - s_max) <= 5e-4 * s_max + 1e-9, n
+    full = params(g, "g.")
+    assert len(full) == 12
+    for k, ref in full.items():
+        assert _rel(sd[k].grad, ref) < GRAD_RTOL, (k, _rel(sd[k].grad, ref))
