@@ -106,3 +106,32 @@ def test_infer_wrapper_matches_reference_padding():
         assert torch.equal(infer.crop_to_mask(a, h, w), crop) and torch.equal(crop, img)
     out = infer.restore(lambda x: x * 2.0 - 0.25, torch.rand(2, 3, 40, 24), factor=16.0)
     assert out.shape == (2, 3, 40, 24) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+
+
+def test_fragment_major_packing_formula_cpu():
+    """packing.pack_frag == the layout formula printed in include/uformer_hip.h, element by element (also with K padded
+    up to a multiple of 32), and packing.pack_rpb_table round-trips a Toeplitz bias and rejects a non-Toeplitz one."""
+    import torch
+    from uformer_amd import packing, spec
+    for (N, K) in ((32, 64), (48, 16), (16, 96)):
+        w = torch.arange(N * K, dtype=torch.float32).reshape(N, K)
+        fm = packing.pack_frag(w, torch.float32).reshape(-1)
+        KS = (K + 31) // 32
+        assert fm.numel() == (N // 16) * KS * 64 * 8
+        for n in range(0, N, 5):
+            for k in range(0, KS * 32, 3):
+                idx = ((n // 16 * KS + k // 32) * 64 + ((k % 32) // 8) * 16 + n % 16) * 8 + k % 8
+                assert fm[idx].item() == (w[n, k].item() if k < K else 0.0), (N, K, n, k)
+    heads = 2
+    table = torch.randn(225, heads)
+    idx = spec.relative_position_index(8)
+    dense = packing.rpb_dense(table, idx)
+    tab = packing.pack_rpb_table(dense)
+    assert tab is not None and tab.shape == (heads, 15, 15)
+    ys, xs = torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    for q in (0, 9, 37, 63):
+        for k in (0, 7, 28, 63):
+            assert tab[1, ys[q] - ys[k] + 7, 7 - (xs[q] - xs[k])] == dense[1, q, k]
+    broken = dense.clone(); broken[0, 3, 5] += 1.0
+    assert packing.pack_rpb_table(broken) is None
