@@ -162,3 +162,36 @@ def test_model_backward_charbonnier(golden):
     assert len(full) == 12
     for k, ref in full.items():
         assert _rel(sd[k].grad, ref) < GRAD_RTOL, (k, _rel(sd[k].grad, ref))
+
+
+def test_explicit_backward_block(golden):
+    """oracle/uformer_oracle_bwd.py (closed-form backward, no autograd) vs the reference's autograd gradients."""
+    from oracle import uformer_oracle_bwd as OB
+    g = golden("grad_lewin_block")
+    p = params(g, "p.")
+    dx, grads = OB.lewin_block_bwd(t(g["x"]), p, "", int(g["heads"]), 4, t(g["gy"]))
+    assert _rel(dx, t(g["dx"])) < GRAD_RTOL
+    ref = params(g, "g.")
+    assert set(grads) == set(ref)
+    for k, r in ref.items():
+        assert _rel(grads[k], r) < GRAD_RTOL, (k, _rel(grads[k], r))
+
+
+def test_explicit_backward_model(golden):
+    from oracle import uformer_oracle_bwd as OB
+    g = golden("grad_model_tiny32_128")
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 1234)
+    x = spec.synth_input(1, 128, 128, 1234)
+    target = spec.synth_input(1, 128, 128, 1235)
+    kw = dict(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    y = O.uformer_forward(x, sd, **kw)
+    dx, grads = OB.uformer_backward(x, sd, OB.charbonnier_loss_bwd(y, target), **kw)
+    assert _rel(dx, t(g["dx"])) < GRAD_RTOL
+    names = [str(n) for n in g["param_names"]]
+    assert set(grads) == set(names)
+    for n, (s_sum, s_abs, s_max) in zip(names, g["grad_stats"]):
+        assert abs(grads[n].abs().sum().item() - s_abs) <= 5e-4 * s_abs + 1e-9, n
+        assert abs(grads[n].abs().max().item() - s_max) <= 5e-4 * s_max + 1e-9, n
+    for k, r in params(g, "g.").items():
+        assert _rel(grads[k], r) < GRAD_RTOL, (k, _rel(grads[k], r))
