@@ -509,15 +509,8 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
     constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            set_error("attn_block: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
-            return UF_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "attn_block")) return rc;
     char name[96] = "";
     if (timing_enabled())
         snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", p.h1 ? "_fc1" : "", sizeof(T) == 2 ? "bf16" : "f32", C, NT, p.n_windows * 64, C);

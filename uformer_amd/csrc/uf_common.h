@@ -189,6 +189,23 @@ int check_launch(const char* what);
 
 // Opt-in timing (uf_timing_enable): brackets one kernel launch with HIP events on its stream and
 // books its algorithmic flops / bytes under `name`.  A no-op (one branch) when disabled.
+// Opt a kernel into its dynamic LDS size, once per (kernel instantiation, device): the attribute belongs to the device's
+// copy of the function, so a process that drives several GPUs has to set it on each (one process per GPU is the normal
+// mode, but the library must not depend on it).  `done` is the call site's static flag array.  Returns UF_OK or sets the
+// thread's error text.
+inline int ensure_dynamic_lds(const void* kernel, int bytes, bool (&done)[64], const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return UF_OK;   // benign race: the attribute call is idempotent
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        set_error("%s: hipFuncSetAttribute(%d B of LDS) failed: %s", what, bytes, hipGetErrorString(e));
+        return UF_ERR_LAUNCH;
+    }
+    done[dev] = true;
+    return UF_OK;
+}
+
 bool timing_enabled();
 struct ScopedTimer {
     ScopedTimer(const char* name, double flops, double bytes, hipStream_t st);

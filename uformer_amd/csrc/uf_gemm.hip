@@ -279,16 +279,8 @@ template <typename T, int BN, int WGM, int WGN, int AL, int EP>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     constexpr int smem = 2 * (BM + BN) * ROWB;
     auto kern = gemm_kernel<T, BN, WGM, WGN, AL, EP>;
-    static bool attr_done = false;  // benign race: the attribute call is idempotent
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            set_error("gemm: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
-            return UF_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "gemm")) return rc;
     const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";

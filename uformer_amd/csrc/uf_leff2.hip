@@ -260,15 +260,8 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
     constexpr int NP = 4, NC = (SZ == 2 && C >= 256) ? 8 : 4;
     constexpr int smem = 2 * 100 * (KC * SZ + 16) + 2 * 64 * (KC * SZ + 16) + 2 * 10 * KC * 4;
     auto kern = leff2_kernel<T, C, NP, NC>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            set_error("leff2: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
-            return UF_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "leff2")) return rc;
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
     if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, NP, NC, M, C, 4 * C);

@@ -336,15 +336,8 @@ int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     auto kern = ln_gemm_kernel<T, C, BM, EP>;
     LnGemmParams p = p_in;
     p.tbuf = debug_get_tbuf();
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        if (e != hipSuccess) {
-            set_error("ln_gemm: hipFuncSetAttribute(%d B) failed: %s", smem, hipGetErrorString(e));
-            return UF_ERR_LAUNCH;
-        }
-        attr_done = true;
-    }
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "ln_gemm")) return rc;
     char name[96] = "";
     if (timing_enabled())
         snprintf(name, sizeof(name), "ln_gemm_%s_%s_c%d_bm%d %dx%dx%d", SZ == 2 ? "bf16" : "f32", EP == EP_QKV ? "qkv" : "fc1", C, BM, p.M, p.N, C);
