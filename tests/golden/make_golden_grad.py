@@ -40,6 +40,44 @@ def main():
          **{"p." + k: v for k, v in blk.state_dict().items()},
          **{"g." + k: p_.grad for k, p_ in blk.named_parameters()})
 
+    # ---------------- per-op gradients: every backward kernel of the next round gets its own reference fixture -----------
+    ops = {}
+
+    def op_grads(tag, module, xin, gy_seed, **fwd_kw):
+        """dx + all parameter gradients of one reference sub-module for a seeded upstream gradient."""
+        xin = xin.clone().requires_grad_(True)
+        out = module(xin, **fwd_kw)
+        gy_ = torch.randn(out.shape, generator=g(gy_seed))
+        out.backward(gy_)
+        ops.update({f"{tag}.x": xin.detach(), f"{tag}.gy": gy_, f"{tag}.y": out.detach(), f"{tag}.dx": xin.grad})
+        ops.update({f"{tag}.p.{k}": v for k, v in module.state_dict().items()})
+        ops.update({f"{tag}.g.{k}": p_.grad for k, p_ in module.named_parameters()})
+
+    attn = ref.WindowAttention(64, (8, 8), 2).eval(); mg.randomize_(attn, 211)
+    blk16 = ref.LeWinTransformerBlock(32, (16, 16), 1, win_size=8, shift_size=4, token_mlp="leff")
+    cap = {}
+    orig = blk16.attn.forward
+    blk16.attn.forward = lambda xx, attn_kv=None, mask=None: (cap.__setitem__("mask", mask.clone()), orig(xx, attn_kv, mask))[1]
+    with torch.no_grad():
+        blk16.eval()(torch.zeros(1, 256, 32))
+    ops["attn.mask"] = cap["mask"]                                        # the SW-MSA mask of a 16x16 map (4 windows)
+    op_grads("attn", attn, torch.randn(8, 64, 64, generator=g(212)), 213, mask=cap["mask"])
+    lf = ref.LeFF(16, 64).eval(); mg.randomize_(lf, 221)
+    op_grads("leff", lf, torch.randn(2, 256, 16, generator=g(222)), 223)
+    dn = ref.Downsample(8, 16).eval(); mg.randomize_(dn, 231)
+    op_grads("down", dn, torch.randn(2, 256, 8, generator=g(232)), 233)
+    up = ref.Upsample(16, 8).eval(); mg.randomize_(up, 241)
+    op_grads("up", up, torch.randn(2, 64, 16, generator=g(242)), 243)
+    ip = ref.InputProj(3, 8, 3, 1, act_layer=torch.nn.LeakyReLU).eval(); mg.randomize_(ip, 251)
+    op_grads("stem", ip, torch.rand(2, 3, 16, 16, generator=g(252)) - 0.3, 253)
+    op = ref.OutputProj(16, 3, 3, 1).eval(); mg.randomize_(op, 261)
+    op_grads("head", op, torch.randn(2, 256, 16, generator=g(262)), 263)
+    ln = torch.nn.LayerNorm(48).eval()
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * torch.randn(48, generator=g(271))); ln.bias.copy_(0.1 * torch.randn(48, generator=g(272)))
+    op_grads("ln", ln, torch.randn(3, 20, 48, generator=g(273)) * 2 + 0.5, 274)
+    save("grad_ops", **ops)
+
     # ---------------- whole tiny32 model, Charbonnier loss ---------------------------------------------------
     cfg = spec.arch_config("tiny32", img_size=128)
     sd = spec.synth_state_dict(cfg, 1234)

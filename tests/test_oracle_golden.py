@@ -195,3 +195,37 @@ def test_explicit_backward_model(golden):
         assert abs(grads[n].abs().max().item() - s_max) <= 5e-4 * s_max + 1e-9, n
     for k, r in params(g, "g.").items():
         assert _rel(grads[k], r) < GRAD_RTOL, (k, _rel(grads[k], r))
+
+
+def test_explicit_backward_per_op(golden):
+    """Every op-level closed form of oracle/uformer_oracle_bwd.py against the reference's autograd on that op alone
+    (tests/golden/grad_ops.npz): the fixtures the individual backward kernels will be tested against."""
+    from oracle import uformer_oracle_bwd as OB
+    g = golden("grad_ops")
+
+    def op(tag):
+        pre = tag + "."
+        return (t(g[pre + "x"]), t(g[pre + "gy"]), t(g[pre + "dx"]), params(g, pre + "p."), params(g, pre + "g."))
+
+    def check(tag, dx, grads, ref_dx, ref_g, strip=""):
+        assert _rel(dx, ref_dx) < GRAD_RTOL, (tag, _rel(dx, ref_dx))
+        got = {k[len(strip):]: v for k, v in grads.items()}
+        assert set(got) == set(ref_g), (tag, sorted(set(got) ^ set(ref_g)))
+        for k, r in ref_g.items():
+            assert _rel(got[k], r) < GRAD_RTOL, (tag, k, _rel(got[k], r))
+
+    x, gy, rdx, p, rg = op("attn")
+    check("attn", *OB.window_attention_bwd(x, p, "", 2, t(g["attn.mask"]), gy), rdx, rg)
+    x, gy, rdx, p, rg = op("leff")
+    check("leff", *OB.leff_bwd(x, p, "", gy), rdx, rg)
+    x, gy, rdx, p, rg = op("down")
+    check("down", *OB.downsample_bwd(x, p, "", gy), rdx, rg)
+    x, gy, rdx, p, rg = op("up")
+    check("up", *OB.upsample_bwd(x, p, "", gy), rdx, rg)
+    x, gy, rdx, p, rg = op("stem")
+    check("stem", *OB.input_proj_bwd(x, {"input_proj." + k: v for k, v in p.items()}, gy), rdx, rg, strip="input_proj.")
+    x, gy, rdx, p, rg = op("head")
+    check("head", *OB.output_proj_bwd(x, {"output_proj." + k: v for k, v in p.items()}, gy), rdx, rg, strip="output_proj.")
+    x, gy, rdx, p, rg = op("ln")
+    dx, dw, db = OB.layer_norm_bwd(x, p["weight"], gy)
+    check("ln", dx, {"weight": dw, "bias": db}, rdx, rg)
