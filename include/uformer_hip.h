@@ -124,6 +124,10 @@ int uf_window_attention_fwd(const void* q, const void* k, const void* vt, const 
  * x,out T[B][H][W][C]; w9 f32[9][C] (tap-major repack of (C,1,3,3)); bias f32[C]. */
 int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B,
                           int H, int W, int C, uf_dtype dtype, void* stream);
+/* the same stencil with the activation optional (gelu = 0: bias may be NULL).  With the taps flipped (w9[8 - t]) and
+ * gelu = 0 it is the INPUT gradient of the depthwise conv: dh[y,x] = sum w[ky,kx] dc[y-ky+1, x-kx+1]. */
+int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H,
+                     int W, int C, int gelu, uf_dtype dtype, void* stream);
 
 /* ---- a10 fused: x += linear2(GELU(dwconv3x3(h1)))  (LeFF second half, model.py:674-683, :987) ----
  * h1 T[B][H][W][4C] = GELU(linear1(LN2(x))); w9 f32[9][4C]; bdw f32[4C]; W2_fm fragment-major T[C][4C]; b2 f32[C];
@@ -194,6 +198,23 @@ int uf_input_proj_fwd(const float* img, const float* w27, const float* bias, flo
 int uf_output_proj_fwd(const float* x, int ld_x, const float* w, const float* bias,
                        const float* img, float* out, int B, int H, int W, int C2, int add_img,
                        void* stream);
+
+/* ---- a15: backward building blocks (autograd of a5 / a10 in the reference; closed forms in
+ * oracle/uformer_oracle_bwd.py, which is pinned to the reference's autograd).  First members of the family; the
+ * rest of the backward path is not built yet.  Token reductions are two-stage through the caller's workspace
+ * (bit-reproducible, no atomics). -------------------------------------------------------------------------- */
+/* dx = dy * GELU'(a), erf form (nn.GELU, model.py:657-660).  a, dy, dx: T[n], n multiple of 16 bytes / sizeof(T) */
+int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype dtype, void* stream);
+/* nn.LayerNorm(C) backward over rows of the f32 stream: dx f32[rows][ld_dx]; dgamma, dbeta f32[C] are OVERWRITTEN
+ * with the sums over all rows.  C in {16,32,64,128,256,512,1024}. */
+size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);
+int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
+                     float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream);
+/* depthwise 3x3 tap / bias gradients: dw9 f32[9][C] (tap-major, like w9), dbias f32[C], OVERWRITTEN;
+ * h (the conv input) and dc (gradient of the conv output, before the bias): T[B][H][W][C], H multiple of 4 */
+size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);
+int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C,
+                       uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a9 (boundary): Uformer.forward (model.py:1269-1305) ------------------------------------ */
 typedef struct uf_model_desc {

@@ -1,0 +1,69 @@
+"""GPU parity of the backward building blocks (row a15) through the C ABI, against the closed forms of
+oracle/uformer_oracle_bwd.py -- which tests/test_oracle_golden.py pins to the reference's own autograd.
+
+Tolerances: f32 2e-4 relative to the largest reference magnitude; bf16 operands 2.5e-2 (inputs/outputs rounded to 8 bits,
+sums in f32)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import uformer_oracle as O
+from oracle import uformer_oracle_bwd as OB
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
+
+
+def rel(a, b):
+    return (a.float().cpu() - b).abs().max().item() / max(1e-12, b.abs().max().item())
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu_bwd(dtype):
+    from uformer_amd import ops
+    a = (torch.randn(3, 50, 64, generator=g(1)) * 2).to(dtype)
+    dy = torch.randn(3, 50, 64, generator=g(2)).to(dtype)
+    ref = dy.float() * OB.gelu_erf_grad(a.float())
+    got = ops.gelu_bwd(a.cuda(), dy.cuda())
+    assert got.dtype == dtype and rel(got, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("C,rows", [(32, 1000), (64, 257), (256, 4096), (512, 130), (1024, 65)])
+def test_layernorm_bwd(C, rows):
+    from uformer_amd import ops
+    x = torch.randn(rows, C, generator=g(3)) * 1.7 + 0.3
+    gamma = 1 + 0.1 * torch.randn(C, generator=g(4))
+    dy = torch.randn(rows, C, generator=g(5))
+    rdx, rdg, rdb = OB.layer_norm_bwd(x, gamma, dy)
+    dx, dg, db = ops.layernorm_bwd(x.cuda(), gamma.cuda(), dy.cuda())
+    assert rel(dx, rdx) < 2e-4 and rel(dg, rdg) < 2e-4 and rel(db, rdb) < 2e-4
+    dx2, dg2, db2 = ops.layernorm_bwd(x.cuda(), gamma.cuda(), dy.cuda())          # two-stage sums: bit-reproducible
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32)])
+def test_dwconv3x3_backward(dtype, B, H, W, C):
+    """Input gradient = the forward stencil with flipped taps (gelu off, no bias); tap / bias gradients = uf_dwconv3x3_wgrad."""
+    from uformer_amd import ops
+    h = torch.randn(B, H, W, C, generator=g(6)).to(dtype)
+    dc = torch.randn(B, H, W, C, generator=g(7)).to(dtype)
+    w = torch.randn(C, 1, 3, 3, generator=g(8)) * 0.3
+    bias = torch.randn(C, generator=g(9)) * 0.1
+    w9 = w.reshape(C, 9).t().contiguous()                                             # tap-major, as packing.pack_dwconv
+    # forward without activation == F.conv2d (checks the gelu = 0 path the backward reuses)
+    ref_c = F.conv2d(h.float().permute(0, 3, 1, 2), w, bias, padding=1, groups=C).permute(0, 2, 3, 1)
+    assert rel(ops.dwconv3x3(h.cuda(), w9.cuda(), bias.cuda(), gelu=False), ref_c) < TOL[dtype]
+    rdh, rdw, rdb = OB.dwconv3x3_bwd(h.float(), w, dc.float())
+    dh = ops.dwconv3x3(dc.cuda(), w9.flip(0).contiguous().cuda(), None, gelu=False)
+    assert rel(dh, rdh) < TOL[dtype]
+    dw9, db = ops.dwconv3x3_wgrad(h.cuda(), dc.cuda())
+    assert rel(dw9, rdw.reshape(C, 9).t()) < (2e-4 if dtype == torch.float32 else 2e-3)   # bf16: inputs exact in f32 sums
+    assert rel(db, rdb) < (2e-4 if dtype == torch.float32 else 2e-3)
+    dw9b, dbb = ops.dwconv3x3_wgrad(h.cuda(), dc.cuda())
+    assert torch.equal(dw9, dw9b) and torch.equal(db, dbb)

@@ -59,6 +59,12 @@ SIGNATURES = {
     "uf_ln_linear_gelu_fwd": (I, [P, I, P, P, P, P, P, I, I, I, I, P]),
     "uf_window_attention_fwd": (I, [P, P, P, P, P, I, P, I, I, I, I, I, I, I, P]),
     "uf_dwconv3x3_gelu_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "uf_dwconv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "uf_gelu_bwd": (I, [P, P, P, C.c_longlong, I, P]),
+    "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),
+    "uf_layernorm_bwd": (I, [P, I, P, P, I, P, I, P, P, I, I, P, c_size_t, P]),
+    "uf_dwconv3x3_wgrad_workspace_bytes": (c_size_t, [I, I]),
+    "uf_dwconv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, c_size_t, P]),
     "uf_dwconv_linear2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "uf_block_workspace_bytes": (c_size_t, [I, I, I]),
     "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),

@@ -1,0 +1,302 @@
+// Backward building blocks, first members of the family.  The reference has no backward
+// code (torch autograd over model.py); the closed forms below are the ones the test suite pins against that autograd.
+//   uf_gelu_bwd            dx = dy * GELU'(a)                                   (nn.GELU, model.py:657-660)
+//   uf_layernorm_bwd       dx, dgamma, dbeta of nn.LayerNorm over the last dim   (model.py:881,888,952,987)
+//   uf_dwconv3x3_wgrad     tap and bias gradients of the depthwise 3x3           (LeFF dwconv, model.py:659)
+// (the INPUT gradient of the depthwise conv is the forward stencil with flipped taps: uf_dwconv3x3_fwd, gelu = 0).
+// All reductions over tokens are two-stage (per-thread partials in a workspace, then a finalize kernel that adds them
+// in a fixed order): bit-reproducible, no atomics.
+#include "uf_internal.h"
+
+namespace uf {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// GELU'(a) = Phi(a) + a phi(a)   (nn.GELU default = erf form, model.py:657-660)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_grad(float a) {
+    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
+}
+
+template <typename T> struct Vec;
+template <> struct Vec<bf16> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16* p, float* f) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float* f) {
+        *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+    }
+};
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float* f) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(p);
+        f[0] = r[0]; f[1] = r[1]; f[2] = r[2]; f[3] = r[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float* f) { *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]}; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ a, const T* __restrict__ dy, T* __restrict__ dx, long long nvec) {
+    constexpr int N = Vec<T>::N;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    float fa[N], fd[N];
+    Vec<T>::load(a + i * N, fa);
+    Vec<T>::load(dy + i * N, fd);
+#pragma unroll
+    for (int k = 0; k < N; ++k) fd[k] *= gelu_grad(fa[k]);
+    Vec<T>::store(dx + i * N, fd);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  xhat = (x-mu)*rstd, g = dy*gamma:
+//   dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  dgamma = sum_rows dy*xhat;  dbeta = sum_rows dy.
+// Row layout as the forward kernel: LPR lanes share a row (DPP all-reduce), RPB rows per workgroup pass; a thread keeps
+// the same channels over all its rows, so dgamma/dbeta accumulate in registers and land in partial[slot][2][C].
+// ---------------------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx,
+                                                            float* __restrict__ partial, int rows) {
+    constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
+    constexpr int V4 = C / (4 * LPR);
+    constexpr int RPB = 256 / LPR;
+    const int sub = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const int nblk = (rows + RPB - 1) / RPB;
+    f32x4 gm[V4], adg[V4], adb[V4];
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        gm[i] = *reinterpret_cast<const f32x4*>(gamma + (i * LPR + sub) * 4);
+        adg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        adb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int mb = blockIdx.x; mb < nblk; mb += gridDim.x) {      // workgroup-uniform trip count
+        const int m = mb * RPB + rl;
+        const bool live = m < rows;
+        const int mc = live ? m : rows - 1;                        // clamped: loads stay unconditional
+        f32x4 v[V4], d[V4];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)mc * ld_x + (i * LPR + sub) * 4);
+            d[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)mc * ld_dy + (i * LPR + sub) * 4);
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mean = allreduce<RedSum, LPR>(sum) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            v[i] -= mean;
+            sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        }
+        const float rstd = 1.0f / sqrtf(allreduce<RedSum, LPR>(sq) * (1.0f / C) + 1e-5f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < V4; ++i) {
+            v[i] *= rstd;                                          // xhat
+            const f32x4 g = d[i] * gm[i];
+            s1 += (g[0] + g[1]) + (g[2] + g[3]);
+            const f32x4 gx = g * v[i];
+            s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+        }
+        s1 = allreduce<RedSum, LPR>(s1) * (1.0f / C);
+        s2 = allreduce<RedSum, LPR>(s2) * (1.0f / C);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                *reinterpret_cast<f32x4*>(dx + (size_t)m * ld_dx + (i * LPR + sub) * 4) = (d[i] * gm[i] - s1 - v[i] * s2) * rstd;
+                adg[i] += d[i] * v[i];
+                adb[i] += d[i];
+            }
+        }
+    }
+    float* out = partial + (size_t)(blockIdx.x * RPB + rl) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < V4; ++i) {
+        *reinterpret_cast<f32x4*>(out + (i * LPR + sub) * 4) = adg[i];
+        *reinterpret_cast<f32x4*>(out + C + (i * LPR + sub) * 4) = adb[i];
+    }
+}
+
+// out[j] = sum_{p < P} partial[p * stride + j], j < n: one thread per output, partials added in index order
+__global__ void column_sum_kernel(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < P; ++p) s += partial[(size_t)p * stride + j];
+    out[j] = s;
+}
+
+constexpr int LN_BWD_MAX_BLOCKS = 512;
+
+// ---------------------------------------------------------------------------------------------------------------
+// depthwise 3x3 weight gradient: dw[t][c] = sum_{b,y,x} dc[b,y,x,c] * h[b, y+ky-1, x+kx-1, c],  db[c] = sum dc.
+// Thread = N channels x a 4-row column strip (as the forward stencil), grid-strided over strips with a stride that is
+// a multiple of the channel-group count, so a thread's channels never change: 10 x N register accumulators per thread,
+// written to partial[thread][10][N]; wgrad_finalize adds the threads that share a channel group.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DWB_R = 4;
+constexpr int DW_WGRAD_BLOCKS = 256;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ h, const T* __restrict__ dc, float* __restrict__ partial,
+                                                              int B, int H, int W, int C) {
+    constexpr int N = Vec<T>::N;
+    const int cv = C / N, strips = H / DWB_R;
+    const long long total = (long long)B * strips * W * cv;
+    const long long gtid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;       // multiple of cv (checked by the launcher)
+    const int c = (int)(gtid % cv) * N;
+    float acc[10][N];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < N; ++i) acc[t][i] = 0.f;
+    for (long long idx = gtid; idx < total; idx += stride) {
+        long long rest = idx / cv;
+        const int xw = (int)(rest % W); rest /= W;
+        const int y0 = (int)(rest % strips) * DWB_R;
+        const int b = (int)(rest / strips);
+        const size_t img = (size_t)b * H * W * C + c;
+        float d[DWB_R][N];
+#pragma unroll
+        for (int r = 0; r < DWB_R; ++r) {
+            Vec<T>::load(dc + img + ((size_t)(y0 + r) * W + xw) * C, d[r]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[9][i] += d[r][i];
+        }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ixr = xw + kx - 1;
+            const float mx = (ixr >= 0 && ixr < W) ? 1.0f : 0.0f;
+            const int ix = ixr < 0 ? 0 : (ixr >= W ? W - 1 : ixr);
+#pragma unroll
+            for (int r = -1; r <= DWB_R; ++r) {            // input row y0 + r pairs with output rows r+1-ky
+                const int iyr = y0 + r;
+                const float m = (iyr >= 0 && iyr < H) ? mx : 0.0f;
+                const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
+                float f[N];
+                Vec<T>::load(h + img + ((size_t)iy * W + ix) * C, f);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = r + 1 - ky;
+                    if (orow < 0 || orow >= DWB_R) continue;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[ky * 3 + kx][i] = fmaf(f[i] * m, d[orow][i], acc[ky * 3 + kx][i]);
+                }
+            }
+        }
+    }
+    float* out = partial + (size_t)gtid * 10 * N;
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[t * N + i] = acc[t][i];
+}
+
+// dw9[t][c] (t < 9) and dbias[c] (t == 9) = sum over the threads j = cg, cg + cv, ... of partial[j][t][c % N]
+__global__ void dwconv3x3_wgrad_finalize(const float* __restrict__ partial, long long nthreads, int cv, int N, float* __restrict__ dw9,
+                                         float* __restrict__ dbias, int C) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // over 10 * C outputs
+    if (j >= 10 * C) return;
+    const int t = j / C, c = j % C, cg = c / N, i = c % N;
+    float s = 0.f;
+    for (long long th = cg; th < nthreads; th += cv) s += partial[(size_t)th * 10 * N + t * N + i];
+    if (t < 9) dw9[(size_t)t * C + c] = s; else dbias[c] = s;
+}
+
+}  // namespace
+}  // namespace uf
+
+using namespace uf;
+
+extern "C" int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(a && dy && dx, UF_ERR_NULL, "uf_gelu_bwd: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_gelu_bwd: dtype %d", (int)dtype);
+    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(n > 0 && n % N == 0, UF_ERR_SHAPE, "uf_gelu_bwd: n=%lld must be a positive multiple of %d", n, N);
+    UF_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0, UF_ERR_ALIGN, "uf_gelu_bwd: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nvec = n / N;
+    const dim3 grid((unsigned)((nvec + 255) / 256));
+    if (dtype == UF_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)dy, (bf16*)dx, nvec);
+    else hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)dy, (float*)dx, nvec);
+    return check_launch("gelu_bwd");
+}
+
+extern "C" size_t uf_layernorm_bwd_workspace_bytes(int rows, int C) {
+    if (rows <= 0 || C < 16) return 0;
+    const int LPR = (C / 4) < 64 ? (C / 4) : 64;
+    return (size_t)LN_BWD_MAX_BLOCKS * (256 / LPR) * 2 * C * sizeof(float);
+}
+
+extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
+                                float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, UF_ERR_NULL, "uf_layernorm_bwd: null pointer");
+    UF_REQUIRE(rows > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, UF_ERR_SHAPE,
+               "uf_layernorm_bwd: rows=%d C=%d ld=(%d,%d,%d)", rows, C, ld_x, ld_dy, ld_dx);
+    UF_REQUIRE(ws_bytes >= uf_layernorm_bwd_workspace_bytes(rows, C), UF_ERR_WORKSPACE, "uf_layernorm_bwd: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)ws;
+    int slots = 0;
+#define UF_LNB_CASE(CV)                                                                                                       \
+    case CV: {                                                                                                                \
+        constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64, RPB = 256 / LPR;                                                   \
+        const int nblk = (rows + RPB - 1) / RPB, grid = nblk < LN_BWD_MAX_BLOCKS ? nblk : LN_BWD_MAX_BLOCKS;                  \
+        slots = grid * RPB;                                                                                                   \
+        hipLaunchKernelGGL(layernorm_bwd_kernel<CV>, dim3(grid), dim3(256), 0, st, x, ld_x, gamma, dy, ld_dy, dx, ld_dx, partial, rows); \
+        break;                                                                                                                \
+    }
+    switch (C) {
+        UF_LNB_CASE(16)
+        UF_LNB_CASE(32)
+        UF_LNB_CASE(64)
+        UF_LNB_CASE(128)
+        UF_LNB_CASE(256)
+        UF_LNB_CASE(512)
+        UF_LNB_CASE(1024)
+        default:
+            set_error("uf_layernorm_bwd: C=%d unsupported (16,32,64,128,256,512,1024)", C);
+            return UF_ERR_UNSUPPORTED;
+    }
+#undef UF_LNB_CASE
+    int rc = check_launch("layernorm_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(column_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, slots, (size_t)2 * C, dgamma, C);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial + C, slots, (size_t)2 * C, dbeta, C);
+    return check_launch("layernorm_bwd_finalize");
+}
+
+extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {
+    const int N = dtype == UF_BF16 ? 8 : 4;
+    if (C <= 0 || C % N) return 0;
+    const int cv = C / N;
+    int blocks = DW_WGRAD_BLOCKS;
+    while (((long long)blocks * 256) % cv) ++blocks;   // stride must be a multiple of the channel-group count
+    return (size_t)blocks * 256 * 10 * N * sizeof(float);
+}
+
+extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C, uf_dtype dtype,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(h && dc && dw9 && dbias && ws, UF_ERR_NULL, "uf_dwconv3x3_wgrad: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_dwconv3x3_wgrad: dtype %d", (int)dtype);
+    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % N == 0 && H % DWB_R == 0, UF_ERR_SHAPE,
+               "uf_dwconv3x3_wgrad: B=%d H=%d W=%d C=%d (C multiple of %d, H multiple of %d)", B, H, W, C, N, DWB_R);
+    UF_REQUIRE((long long)B * H * W * C < 0x7fffffffLL, UF_ERR_SHAPE, "uf_dwconv3x3_wgrad: tensor too large");
+    const size_t need = uf_dwconv3x3_wgrad_workspace_bytes(C, dtype);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_dwconv3x3_wgrad: workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int cv = C / N;
+    const int blocks = (int)(need / (256 * 10 * N * sizeof(float)));
+    if (dtype == UF_BF16) hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)h, (const bf16*)dc, (float*)ws, B, H, W, C);
+    else hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (const float*)dc, (float*)ws, B, H, W, C);
+    int rc = check_launch("dwconv3x3_wgrad");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dwconv3x3_wgrad_finalize, dim3((10 * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (long long)blocks * 256, cv, N, dw9, dbias, C);
+    return check_launch("dwconv3x3_wgrad_finalize");
+}

@@ -111,7 +111,7 @@ template <> struct Vec16<float> {
 // once per (column tap) and feeds up to 3 output rows, the 3 column-tap weights live in registers.
 constexpr int DW_R = 4;
 
-template <typename T>
+template <typename T, bool ACT>   // ACT: + GELU (the LeFF forward); without it the same stencil serves the backward (flipped taps)
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict__ x, const float* __restrict__ w9,
                                                              const float* __restrict__ bias, T* __restrict__ out, int B, int H,
                                                              int W, int C) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
 #pragma unroll
     for (int r = 0; r < DW_R; ++r)
 #pragma unroll
-        for (int i = 0; i < N; ++i) acc[r][i] = bias[c + i];
+        for (int i = 0; i < N; ++i) acc[r][i] = bias ? bias[c + i] : 0.0f;
     const T* xb = x + (size_t)b * H * W * C + c;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
     }
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) {
-        gelu_n<T, N>(acc[r]);
+        if constexpr (ACT) gelu_n<T, N>(acc[r]);
         Vec16<T>::store(out + ((size_t)(b * H + y0 + r) * W + xw) * C + c, acc[r]);
     }
 }
@@ -421,27 +421,40 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
     return launch_layernorm(x, ld_x, gamma, beta, modulator, out, B * H * W, H, W, C, windowed, shift, dtype, (hipStream_t)stream);
 }
 
-extern "C" int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C,
-                                     uf_dtype dtype, void* stream) {
-    UF_REQUIRE(x && w9 && bias && out, UF_ERR_NULL, "uf_dwconv3x3_gelu_fwd: null pointer");
-    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: bad shape (H must be a multiple of %d)", DW_R);
+// gelu != 0: depthwise 3x3 + bias + GELU (LeFF forward, model.py:659-660).  gelu == 0: the bare stencil (bias may be
+// NULL) -- with the taps flipped (w9[8 - t]) it is the INPUT gradient of the same convolution:
+// dh[y,x] = sum_{ky,kx} w[ky,kx] dc[y-ky+1, x-kx+1].
+extern "C" int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C, int gelu,
+                                uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w9 && out && (bias || !gelu), UF_ERR_NULL, "uf_dwconv3x3_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: bad shape (H must be a multiple of %d)", DW_R);
     hipStream_t st = (hipStream_t)stream;
     char tname[64] = "";
-    if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3_gelu %dx%d", B * H * W, C);
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3%s %dx%d", gelu ? "_gelu" : "", B * H * W, C);
     ScopedTimer tm(tname, 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), st);
     if (dtype == UF_BF16) {
-        UF_REQUIRE(C % 8 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 8", C);
+        UF_REQUIRE(C % 8 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: C=%d must be a multiple of 8", C);
         const long long n = (long long)B * (H / DW_R) * W * (C / 8);
-        hipLaunchKernelGGL(dwconv3x3_gelu_kernel<bf16>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (gelu) hipLaunchKernelGGL((dwconv3x3_gelu_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
+        else hipLaunchKernelGGL((dwconv3x3_gelu_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
     } else if (dtype == UF_F32) {
-        UF_REQUIRE(C % 4 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_gelu_fwd: C=%d must be a multiple of 4", C);
+        UF_REQUIRE(C % 4 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: C=%d must be a multiple of 4", C);
         const long long n = (long long)B * (H / DW_R) * W * (C / 4);
-        hipLaunchKernelGGL(dwconv3x3_gelu_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
+        const dim3 grid((unsigned)((n + 255) / 256));
+        if (gelu) hipLaunchKernelGGL((dwconv3x3_gelu_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
+        else hipLaunchKernelGGL((dwconv3x3_gelu_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
     } else {
-        set_error("uf_dwconv3x3_gelu_fwd: dtype %d", (int)dtype);
+        set_error("uf_dwconv3x3_fwd: dtype %d", (int)dtype);
         return UF_ERR_UNSUPPORTED;
     }
-    return check_launch("dwconv3x3_gelu");
+    return check_launch("dwconv3x3");
+}
+
+extern "C" int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C,
+                                     uf_dtype dtype, void* stream) {
+    UF_REQUIRE(bias, UF_ERR_NULL, "uf_dwconv3x3_gelu_fwd: null pointer");
+    return uf_dwconv3x3_fwd(x, w9, bias, out, B, H, W, C, 1, dtype, stream);
 }
 
 extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float* bias, float* out, int ld_o, int B, int Cin,

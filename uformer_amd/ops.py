@@ -224,6 +224,67 @@ def dwconv3x3_gelu(x: Tensor, w9: Tensor, bias: Tensor) -> Tensor:
     return out
 
 
+def dwconv3x3(x: Tensor, w9: Tensor, bias: Optional[Tensor] = None, gelu: bool = False) -> Tensor:
+    """The depthwise 3x3 stencil with optional bias / GELU.  With ``w9.flip(0)`` (taps flipped), no bias and no GELU it is
+    the input gradient of the convolution."""
+    _dev(x, w9)
+    dt = uf_dtype(x.dtype)
+    x = _c(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    b = _c(bias, torch.float32) if bias is not None else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_dwconv3x3_fwd(_ptr(x), _ptr(_c(w9, torch.float32)), _ptr(b) if b is not None else None, _ptr(out),
+                                                B, H, W, Cc, 1 if gelu else 0, dt, _stream()), "uf_dwconv3x3_fwd")
+    return out
+
+
+def gelu_bwd(a: Tensor, dy: Tensor) -> Tensor:
+    """dy * GELU'(a), erf form (backward of nn.GELU, model.py:657-660).  a, dy: same shape and dtype (bf16 / f32)."""
+    _dev(a, dy)
+    dt = uf_dtype(a.dtype)
+    a, dy = _c(a), _c(dy, a.dtype)
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_gelu_bwd(_ptr(a), _ptr(dy), _ptr(out), a.numel(), dt, _stream()), "uf_gelu_bwd")
+    return out
+
+
+def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor):
+    """Backward of nn.LayerNorm over the last dim of f32 rows: returns (dx, dgamma, dbeta).  model.py:881,888."""
+    _dev(x, gamma, dy)
+    Cc = x.shape[-1]
+    x2, dy2 = _c(x, torch.float32).reshape(-1, Cc), _c(dy, torch.float32).reshape(-1, Cc)
+    rows = x2.shape[0]
+    dx = torch.empty_like(x2)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_layernorm_bwd_workspace_bytes(rows, Cc)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_layernorm_bwd(_ptr(x2), Cc, _ptr(_c(gamma, torch.float32)), _ptr(dy2), Cc, _ptr(dx), Cc, _ptr(dg), _ptr(db),
+                                        rows, Cc, _ptr(ws), nbytes, _stream()), "uf_layernorm_bwd")
+    return dx.reshape(x.shape), dg, db
+
+
+def dwconv3x3_wgrad(h: Tensor, dc: Tensor):
+    """Tap (9,C) and bias (C,) gradients of the depthwise 3x3 from its input h and output gradient dc, both T(B,H,W,C)."""
+    _dev(h, dc)
+    dt = uf_dtype(h.dtype)
+    h, dc = _c(h), _c(dc, h.dtype)
+    B, H, W, Cc = h.shape
+    dw9 = torch.empty(9, Cc, dtype=torch.float32, device=h.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=h.device)
+    lib = _lib.load()
+    nbytes = lib.uf_dwconv3x3_wgrad_workspace_bytes(Cc, dt)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=h.device)
+    with torch.cuda.device(h.device):
+        _lib.check(lib.uf_dwconv3x3_wgrad(_ptr(h), _ptr(dc), _ptr(dw9), _ptr(db), B, H, W, Cc, dt, _ptr(ws), nbytes, _stream()),
+                   "uf_dwconv3x3_wgrad")
+    return dw9, db
+
+
 def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
     """x + linear2(GELU(dwconv3x3(h1))) (model.py:674-683, :987).  h1 T(B,H,W,4C); x f32 (B*H*W, C); returns new x."""
     _dev(h1, w9, bdw, w2, b2, x)
