@@ -210,6 +210,12 @@ int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype d
 size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);
 int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
                      float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream);
+/* nn.Linear weight / bias gradients: dW f32[N][K] = sum_m dY[m][n] X[m][k], db f32[N] = sum_m dY[m][n] (db may be NULL),
+ * OVERWRITTEN.  dY T[M][ldy] (N columns), X T[M][ldx] (K columns); N, K, ldy, ldx multiples of 16 bytes / sizeof(T).
+ * (The input gradient dX = dY W is uf_linear_fwd with the transposed weight.) */
+size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K);
+int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
+                    uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 /* depthwise 3x3 tap / bias gradients: dw9 f32[9][C] (tap-major, like w9), dbias f32[C], OVERWRITTEN;
  * h (the conv input) and dc (gradient of the conv output, before the bias): T[B][H][W][C], H multiple of 4 */
 size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);

@@ -67,3 +67,21 @@ def test_dwconv3x3_backward(dtype, B, H, W, C):
     assert rel(db, rdb) < (2e-4 if dtype == torch.float32 else 2e-3)
     dw9b, dbb = ops.dwconv3x3_wgrad(h.cuda(), dc.cuda())
     assert torch.equal(dw9, dw9b) and torch.equal(db, dbb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512)])
+def test_linear_wgrad_and_input_grad(dtype, M, N, K):
+    """dW = dY^T X, db = column sums (token-split MFMA kernel, two-stage sums) and dX = dY W through the forward GEMM."""
+    from uformer_amd import ops
+    x = torch.randn(M, K, generator=g(10)).to(dtype)
+    dy = torch.randn(M, N, generator=g(11)).to(dtype)
+    w = (torch.randn(N, K, generator=g(12)) / K ** 0.5).to(dtype)
+    rdx, rdw, rdb = OB.linear_bwd(x.float(), w.float(), dy.float())
+    dW, db = ops.linear_wgrad(dy.cuda(), x.cuda())
+    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    assert rel(dW, rdw) < tol and rel(db, rdb) < tol
+    dW2, db2 = ops.linear_wgrad(dy.cuda(), x.cuda())
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    dx = ops.linear(dy.cuda(), w.t().contiguous().cuda(), torch.zeros(K).cuda())      # dX = dY W: the forward kernel, transposed weight
+    assert rel(dx, rdx) < TOL[dtype]

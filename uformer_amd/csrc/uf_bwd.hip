@@ -209,6 +209,107 @@ __global__ void dwconv3x3_wgrad_finalize(const float* __restrict__ partial, long
     if (t < 9) dw9[(size_t)t * C + c] = s; else dbias[c] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// nn.Linear weight / bias gradients:  dW[n][k] = sum_m dY[m][n] X[m][k],  db[n] = sum_m dY[m][n]   (linear_bwd).
+// The contraction runs over TOKENS, so both MFMA operands need 8 consecutive tokens of ONE column per lane: a step
+// stages dY[32 tokens][64 n] and X[32 tokens][64 k] transposed into LDS ([column][token]) and each wave issues 2 x 2
+// MFMAs on its 32 x 32 quadrant of the 64 x 64 output tile.  blockIdx.y cuts the tokens into gridDim.y chunks; partial
+// tiles go to ws[chunk][N][K] (db: ws_b[chunk][N]) and column_sum_kernel adds the chunks in order (bit-reproducible).
+// First version: LDS-write bound (2-byte transposing stores); the transposing LDS reads of gfx950 are the next step.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ X, int ldx,
+                                                           float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K) {
+    constexpr int SZ = sizeof(T), EP = 16 / SZ;            // elements per 16-byte piece
+    constexpr int PPR = 64 / EP;                            // pieces per 64-column row
+    constexpr int PPT = 32 * PPR / 256;                     // pieces per thread and operand per step (1 bf16, 2 f32)
+    constexpr int STR = 32 * SZ + 16;                       // LDS row stride of a [column][32 tokens] tile
+    __shared__ __attribute__((aligned(16))) char Yt[64 * STR];
+    __shared__ __attribute__((aligned(16))) char Xt[64 * STR];
+    __shared__ float Bs[32][64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k_tiles = (K + 63) / 64;
+    const int n0 = (blockIdx.x / k_tiles) * 64, k0 = (blockIdx.x % k_tiles) * 64;
+    const int wn = wave >> 1, wk = wave & 1;                // 32 x 32 quadrant of this wave
+    const bool do_bias = (blockIdx.x % k_tiles) == 0;       // one k-tile column of blocks also sums dY
+    // token range of this chunk, in steps of 32
+    const int steps_all = (M + 31) / 32;
+    const int s0 = (int)((long long)steps_all * blockIdx.y / gridDim.y), s1 = (int)((long long)steps_all * (blockIdx.y + 1) / gridDim.y);
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum[PPT][EP];
+#pragma unroll
+    for (int q = 0; q < PPT; ++q)
+#pragma unroll
+        for (int e = 0; e < EP; ++e) bsum[q][e] = 0.f;
+
+    for (int s = s0; s < s1; ++s) {
+        const int m0 = s * 32;
+        // ---- stage: every thread moves PPT 16-byte pieces of each operand, transposing on the way into LDS
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pc = tid + 256 * q, r = pc / PPR, pp = pc % PPR;      // token row in the step, piece in the row
+            const int m = m0 + r;
+            const float live = m < M ? 1.0f : 0.0f;
+            const int mc = m < M ? m : M - 1;
+            const int cn = n0 + pp * EP, ck = k0 + pp * EP;
+            float fy[EP], fx[EP];
+            Vec<T>::load(dY + (size_t)mc * ldy + (cn < N ? cn : N - EP), fy);   // clamped, unconditional
+            Vec<T>::load(X + (size_t)mc * ldx + (ck < K ? ck : K - EP), fx);
+            const float my = (cn < N) ? live : 0.0f, mx = (ck < K) ? live : 0.0f;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) {
+                store1(reinterpret_cast<T*>(Yt + (pp * EP + e) * STR) + r, fy[e] * my);
+                store1(reinterpret_cast<T*>(Xt + (pp * EP + e) * STR) + r, fx[e] * mx);
+                bsum[q][e] += fy[e] * my;
+            }
+        }
+        __syncthreads();
+        // ---- 2 x 2 MFMAs: A = dY^T rows n (8 tokens of lane group fg), B = X^T rows k, same token slots
+        Frag<T> a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_frag(a[i], reinterpret_cast<const T*>(Yt + (wn * 32 + i * 16 + fr) * STR) + fg * 8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) load_frag(b[j], reinterpret_cast<const T*>(Xt + (wk * 32 + j * 16 + fr) * STR) + fg * 8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(acc[i][j], a[i], b[j]);
+        __syncthreads();
+    }
+    // ---- partial tile: D row = 4*fg + reg -> n, col = fr -> k
+    float* wp = ws_w + (size_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + i * 16 + fg * 4 + r, k = k0 + wk * 32 + j * 16 + fr;
+                if (n < N && k < K) wp[(size_t)n * K + k] = acc[i][j][r];
+            }
+    if (do_bias) {   // column sums of this chunk's dY tile: the 32 token-row threads of a piece meet in LDS
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int pc = tid + 256 * q, r = pc / PPR, pp = pc % PPR;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) Bs[r][pp * EP + e] = bsum[q][e];
+        }
+        __syncthreads();
+        if (tid < 64 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) t += Bs[r][tid];
+            ws_b[(size_t)blockIdx.y * N + n0 + tid] = t;
+        }
+    }
+}
+
 }  // namespace
 }  // namespace uf
 
@@ -299,4 +400,47 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     if (rc) return rc;
     hipLaunchKernelGGL(dwconv3x3_wgrad_finalize, dim3((10 * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (long long)blocks * 256, cv, N, dw9, dbias, C);
     return check_launch("dwconv3x3_wgrad_finalize");
+}
+
+static int wgrad_chunks(int M, int N, int K) {
+    const int tiles = ((N + 63) / 64) * ((K + 63) / 64), steps = (M + 31) / 32;
+    int S = 2048 / tiles;
+    if (S > steps) S = steps;
+    if (S > 256) S = 256;
+    return S < 1 ? 1 : S;
+}
+
+extern "C" size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return (size_t)wgrad_chunks(M, N, K) * ((size_t)N * K + N) * sizeof(float);
+}
+
+extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
+                               uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(dY && X && dW && ws, UF_ERR_NULL, "uf_linear_wgrad: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_linear_wgrad: dtype %d", (int)dtype);
+    const int EP = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(M > 0 && N >= EP && K >= EP && N % EP == 0 && K % EP == 0 && ldy >= N && ldx >= K && ldy % EP == 0 && ldx % EP == 0, UF_ERR_SHAPE,
+               "uf_linear_wgrad: M=%d N=%d K=%d ld=(%d,%d) (N, K, ld multiples of %d)", M, N, K, ldy, ldx, EP);
+    UF_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, UF_ERR_ALIGN, "uf_linear_wgrad: operands must be 16-byte aligned");
+    const size_t need = uf_linear_wgrad_workspace_bytes(M, N, K);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_linear_wgrad: workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int S = wgrad_chunks(M, N, K);
+    float* ws_w = (float*)ws;
+    float* ws_b = ws_w + (size_t)S * N * K;
+    const dim3 grid(((N + 63) / 64) * ((K + 63) / 64), S);
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype == UF_BF16 ? "bf16" : "f32", M, N, K);
+    {
+        ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
+        if (dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
+        else hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, ws_w, ws_b, M, N, K);
+    }
+    int rc = check_launch("linear_wgrad");
+    if (rc) return rc;
+    const int nk = N * K;
+    hipLaunchKernelGGL(column_sum_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
+    if (db) hipLaunchKernelGGL(column_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws_b, S, (size_t)N, db, N);
+    return check_launch("linear_wgrad_finalize");
 }

@@ -268,6 +268,25 @@ def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor):
     return dx.reshape(x.shape), dg, db
 
 
+def linear_wgrad(dy: Tensor, x: Tensor, with_bias: bool = True):
+    """nn.Linear parameter gradients from the output gradient dy (..., N) and the layer input x (..., K), same dtype
+    (bf16 / f32): returns (dW f32 (N,K), db f32 (N,) or None).  The input gradient is ``linear(dy, W.t())``."""
+    _dev(dy, x)
+    dt = uf_dtype(x.dtype)
+    N, K = dy.shape[-1], x.shape[-1]
+    dy2, x2 = _c(dy, x.dtype).reshape(-1, N), _c(x).reshape(-1, K)
+    M = x2.shape[0]
+    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if with_bias else None
+    lib = _lib.load()
+    nbytes = lib.uf_linear_wgrad_workspace_bytes(M, N, K)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_linear_wgrad(_ptr(dy2), N, _ptr(x2), K, _ptr(dW), _ptr(db) if db is not None else None, M, N, K, dt,
+                                       _ptr(ws), nbytes, _stream()), "uf_linear_wgrad")
+    return dW, db
+
+
 def dwconv3x3_wgrad(h: Tensor, dc: Tensor):
     """Tap (9,C) and bias (C,) gradients of the depthwise 3x3 from its input h and output gradient dc, both T(B,H,W,C)."""
     _dev(h, dc)
