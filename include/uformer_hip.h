@@ -216,6 +216,16 @@ int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* 
 size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K);
 int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
                     uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* Window attention backward (a8, model.py:494-519 without the projections), everything recomputed from the forward
+ * operands of uf_window_attention_fwd: q (scaled), k T[n_windows*heads][64][hd], vt T[..][hd][64], bias_dense, mask.
+ * dO T[n_windows*64][ldo] is the gradient of the merged-head output.  dq, dk, dvt: gradients wrt q (as stored, i.e.
+ * scaled), k, vt, same layouts; dbias f32[heads][64][64] = dS summed over all windows (OVERWRITTEN; scatter-add it
+ * through relative_position_index for the table gradient).  head_dim 32. */
+size_t uf_window_attention_bwd_workspace_bytes(int n_windows, int heads);
+int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask,
+                            int n_mask, const void* dO, int ldo, void* dq, void* dk, void* dvt, float* dbias,
+                            int n_windows, int heads, int head_dim, int H, int W, int shift, uf_dtype dtype,
+                            void* ws, size_t ws_bytes, void* stream);
 /* depthwise 3x3 tap / bias gradients: dw9 f32[9][C] (tap-major, like w9), dbias f32[C], OVERWRITTEN;
  * h (the conv input) and dc (gradient of the conv output, before the bias): T[B][H][W][C], H multiple of 4 */
 size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);

@@ -85,3 +85,44 @@ def test_linear_wgrad_and_input_grad(dtype, M, N, K):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
     dx = ops.linear(dy.cuda(), w.t().contiguous().cuda(), torch.zeros(K).cuda())      # dX = dY W: the forward kernel, transposed weight
     assert rel(dx, rdx) < TOL[dtype]
+
+
+def _attention_bwd_reference(q, k, v, bias, mask, do, heads):
+    """Closed form of the attention core's backward (the same algebra as OB.window_attention_bwd, without projections).
+    q (scaled), k, v: (nW, heads, 64, hd); bias (heads,64,64); mask (nM,64,64) or None; do (nW, heads, 64, hd)."""
+    s = q @ k.transpose(-2, -1) + bias.unsqueeze(0)
+    if mask is not None:
+        nW, nM = s.shape[0], mask.shape[0]
+        s = (s.reshape(nW // nM, nM, heads, 64, 64) + mask.unsqueeze(1).unsqueeze(0)).reshape(nW, heads, 64, 64)
+    P = torch.softmax(s, dim=-1)
+    dv = P.transpose(-2, -1) @ do
+    dP = do @ v.transpose(-2, -1)
+    dS = P * (dP - (dP * P).sum(-1, keepdim=True))
+    return dS @ k, dS.transpose(-2, -1) @ q, dv, dS.sum(0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,heads,shift", [(2, 16, 2, 4), (1, 32, 1, 0), (3, 16, 4, 4), (5, 8, 2, 0)])
+def test_window_attention_bwd(dtype, B, H, heads, shift):
+    from uformer_amd import ops
+    nW = B * (H // 8) ** 2
+    hd, C = 32, heads * 32
+    q = (torch.randn(nW, heads, 64, hd, generator=g(20)) * hd ** -0.5).to(dtype)       # the forward stores q already scaled
+    k = torch.randn(nW, heads, 64, hd, generator=g(21)).to(dtype)
+    v = torch.randn(nW, heads, 64, hd, generator=g(22)).to(dtype)
+    do = torch.randn(nW, heads, 64, hd, generator=g(23)).to(dtype)
+    bias = torch.randn(heads, 64, 64, generator=g(24)) * 0.3
+    mask = O.shift_attn_mask(H, H, 8, 4) if shift else None
+    rdq, rdk, rdv, rdb = _attention_bwd_reference(q.float(), k.float(), v.float(), bias, mask, do.float(), heads)
+    flat = lambda t: t.reshape(nW * heads, 64, hd).contiguous()                        # noqa: E731
+    do_rows = do.permute(0, 2, 1, 3).reshape(nW * 64, C).contiguous()                  # merged heads, token rows
+    dq, dk, dvt, dbias = ops.window_attention_bwd(flat(q).cuda(), flat(k).cuda(), flat(v).transpose(1, 2).contiguous().cuda(),
+                                                  bias.cuda(), do_rows.cuda(), H, H, shift)       # analytic SW-MSA mask
+    tol = TOL[dtype]
+    assert rel(dq, flat(rdq)) < tol and rel(dk, flat(rdk)) < tol
+    assert rel(dvt, flat(rdv).transpose(1, 2)) < tol
+    assert rel(dbias, rdb) < tol
+    if shift:   # the dense-mask argument must give the same result as the analytic mask
+        dq2, dk2, dvt2, db2 = ops.window_attention_bwd(flat(q).cuda(), flat(k).cuda(), flat(v).transpose(1, 2).contiguous().cuda(),
+                                                       bias.cuda(), do_rows.cuda(), H, H, 0, mask=mask.cuda())
+        assert rel(dq2, flat(rdq)) < tol and rel(db2, rdb) < tol

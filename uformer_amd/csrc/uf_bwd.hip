@@ -310,6 +310,174 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Window attention backward (WindowAttention.forward, model.py:494-519, without the projections):
+//   P = softmax(q k^T + bias + mask);   dV = P^T dO;   dP = dO V^T;   dS = P o (dP - rowsum(dP o P));
+//   dq = dS k;   dk = dS^T q;   dbias[h] = sum over windows of dS        (q is the SCALED query the forward stores)
+// One workgroup per (head, chunk of windows), 4 waves; everything is recomputed from q, k, v^T.  All five products run
+// on the MFMA with BOTH operands read from LDS tiles kept in the orientation the product needs ([row][contraction index]),
+// so each tile exists token-major and d-major, and P / dS in both orientations -- simple and layout-safe; chaining the
+// accumulators into the next operands as the forward kernel does is the follow-up.  Wave w owns query rows 16w..16w+15 of
+// S, P, dP, dS (softmax row statistics: 4 in-lane tiles + a 16-lane DPP reduction) and keeps its slice of dbias in
+// registers across the windows of the chunk.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
+                                                              const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
+                                                              const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
+                                                              T* __restrict__ dvt, float* __restrict__ ws_bias, int n_windows, int heads,
+                                                              int H, int W, int shift) {
+    constexpr int HD = 32, SZ = sizeof(T), EP = 16 / SZ;
+    constexpr int SD = HD * SZ + 16, ST = 64 * SZ + 16;       // row strides: [token][d] tiles, [d or token][token] tiles
+    constexpr int PPT = 64 * HD / EP / 256;                   // 16-byte pieces per thread and tile (1 bf16, 2 f32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                 char* Ks = Qs + 64 * SD;  char* Vs = Ks + 64 * SD;  char* Gs = Vs + 64 * SD;   // token-major
+    char* QT = Gs + 64 * SD;         char* KT = QT + HD * ST;  char* GT = KT + HD * ST;                              // d-major
+    char* Ps = GT + HD * ST;         char* PT = Ps + 64 * ST;  char* Ds = PT + 64 * ST;  char* DT = Ds + 64 * ST;   // 64 x 64
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.x;
+    const int w0 = (int)((long long)n_windows * blockIdx.y / gridDim.y), w1 = (int)((long long)n_windows * (blockIdx.y + 1) / gridDim.y);
+    const int i0 = wave * 16;
+    const int nWc = W >> 3, nW = (H >> 3) * nWc;
+
+    // bias of this wave's rows, cached for all windows: element (t, r) = bias[h][i0 + 4fg + r][16t + fr]
+    float br[4][4];
+    f32x4 adb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        adb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) br[t][r] = bias_dense[(size_t)h * 4096 + (i0 + 4 * fg + r) * 64 + 16 * t + fr];
+    }
+
+    for (int bw = w0; bw < w1; ++bw) {
+        const size_t base = ((size_t)bw * heads + h) * (64 * HD);
+        // ---- stage q, k, dO (token-major + transposed) and v (from v^T, transposed back to token-major)
+#pragma unroll
+        for (int pq = 0; pq < PPT; ++pq) {
+            const int pc = tid + 256 * pq;
+            {
+                const int i = pc / (HD / EP), pp = pc % (HD / EP);           // token row, piece of the 32 d
+                float fq[EP], fk[EP], fgd[EP];
+                Vec<T>::load(q + base + i * HD + pp * EP, fq);
+                Vec<T>::load(k + base + i * HD + pp * EP, fk);
+                Vec<T>::load(dO + ((size_t)bw * 64 + i) * ldo + h * HD + pp * EP, fgd);
+                Vec<T>::store(reinterpret_cast<T*>(Qs + i * SD) + pp * EP, fq);
+                Vec<T>::store(reinterpret_cast<T*>(Ks + i * SD) + pp * EP, fk);
+                Vec<T>::store(reinterpret_cast<T*>(Gs + i * SD) + pp * EP, fgd);
+#pragma unroll
+                for (int e = 0; e < EP; ++e) {
+                    store1(reinterpret_cast<T*>(QT + (pp * EP + e) * ST) + i, fq[e]);
+                    store1(reinterpret_cast<T*>(KT + (pp * EP + e) * ST) + i, fk[e]);
+                    store1(reinterpret_cast<T*>(GT + (pp * EP + e) * ST) + i, fgd[e]);
+                }
+            }
+            {
+                const int d = pc / (64 / EP), pp = pc % (64 / EP);           // d row of v^T, piece of the 64 tokens
+                float fv[EP];
+                Vec<T>::load(vt + base + d * 64 + pp * EP, fv);
+#pragma unroll
+                for (int e = 0; e < EP; ++e) store1(reinterpret_cast<T*>(Vs + (pp * EP + e) * SD) + d, fv[e]);
+            }
+        }
+        __syncthreads();
+
+        // ---- this wave's 16 query rows: S = q k^T and dP = dO v^T (one MFMA k-step: d = 32), then softmax algebra
+        Frag<T> aq, ag, bk[4], bv[4];
+        load_frag(aq, reinterpret_cast<const T*>(Qs + (i0 + fr) * SD) + fg * 8);
+        load_frag(ag, reinterpret_cast<const T*>(Gs + (i0 + fr) * SD) + fg * 8);
+        f32x4 sc[4], dp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            load_frag(bk[t], reinterpret_cast<const T*>(Ks + (16 * t + fr) * SD) + fg * 8);
+            load_frag(bv[t], reinterpret_cast<const T*>(Vs + (16 * t + fr) * SD) + fg * 8);
+            sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            mma16(sc[t], aq, bk[t]);       // D[row = 4fg + r -> query i0+4fg+r][col = fr -> key 16t+fr]
+            mma16(dp[t], ag, bv[t]);
+        }
+        const int wi = bw % nW;
+        const bool last_r = shift > 0 && (wi / nWc) == (H >> 3) - 1;
+        const bool last_c = shift > 0 && (wi % nWc) == nWc - 1;
+        const float* mk = mask ? mask + (size_t)(bw % n_mask) * 4096 : nullptr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qi = i0 + 4 * fg + r;
+            const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int kj = 16 * t + fr;
+                float v = sc[t][r] + br[t][r];
+                if (mk) v += mk[qi * 64 + kj];
+                // SW-MSA mask, model.py:924-942: -100 where the region ids of query and key differ
+                const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;
+                if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                sc[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = allreduce<RedMax, 16>(mx);                       // the 16 lanes of a lane group hold one query row
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { sc[t][r] = __expf(sc[t][r] - mx); sum += sc[t][r]; }
+            const float inv = 1.0f / allreduce<RedSum, 16>(sum);
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { sc[t][r] *= inv; dot += sc[t][r] * dp[t][r]; }
+            dot = allreduce<RedSum, 16>(dot);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float ds = sc[t][r] * (dp[t][r] - dot);
+                adb[t][r] += ds;
+                const int kj = 16 * t + fr;
+                store1(reinterpret_cast<T*>(Ps + qi * ST) + kj, sc[t][r]);
+                store1(reinterpret_cast<T*>(PT + kj * ST) + qi, sc[t][r]);
+                store1(reinterpret_cast<T*>(Ds + qi * ST) + kj, ds);
+                store1(reinterpret_cast<T*>(DT + kj * ST) + qi, ds);
+            }
+        }
+        __syncthreads();
+
+        // ---- dq[i][d] = sum_j dS[i][j] k[j][d];  dk[j][d] = sum_i dS[i][j] q[i][d];  dv^T[d][j] = sum_i dO[i][d] P[i][j]
+        // wave w: 16-row tile w of dq and dk (both d tiles), 16-column tile w of dv^T (both d tiles); 64-long contraction
+        f32x4 oq[2], ok[2], ov[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { oq[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[c] = oq[c]; ov[c] = oq[c]; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Frag<T> a_ds, a_dst, b_pt;
+            load_frag(a_ds, reinterpret_cast<const T*>(Ds + (i0 + fr) * ST) + ks * 32 + fg * 8);      // rows i, slots j
+            load_frag(a_dst, reinterpret_cast<const T*>(DT + (i0 + fr) * ST) + ks * 32 + fg * 8);     // rows j, slots i
+            load_frag(b_pt, reinterpret_cast<const T*>(PT + (i0 + fr) * ST) + ks * 32 + fg * 8);      // cols j, slots i
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                Frag<T> b_kt, b_qt, a_gt;
+                load_frag(b_kt, reinterpret_cast<const T*>(KT + (16 * c + fr) * ST) + ks * 32 + fg * 8);   // cols d, slots j
+                load_frag(b_qt, reinterpret_cast<const T*>(QT + (16 * c + fr) * ST) + ks * 32 + fg * 8);   // cols d, slots i
+                load_frag(a_gt, reinterpret_cast<const T*>(GT + (16 * c + fr) * ST) + ks * 32 + fg * 8);   // rows d, slots i
+                mma16(oq[c], a_ds, b_kt);      // D[row i][col d]
+                mma16(ok[c], a_dst, b_qt);     // D[row j][col d]
+                mma16(ov[c], a_gt, b_pt);      // D[row d][col j]
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                store1(dq + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, oq[c][r]);
+                store1(dk + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, ok[c][r]);
+                store1(dvt + base + (16 * c + 4 * fg + r) * 64 + i0 + fr, ov[c][r]);
+            }
+        __syncthreads();   // the next window overwrites the tiles
+    }
+    float* wb = ws_bias + ((size_t)blockIdx.y * heads + h) * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wb[(i0 + 4 * fg + r) * 64 + 16 * t + fr] = adb[t][r];
+}
+
 }  // namespace
 }  // namespace uf
 
@@ -443,4 +611,58 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     hipLaunchKernelGGL(column_sum_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
     if (db) hipLaunchKernelGGL(column_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws_b, S, (size_t)N, db, N);
     return check_launch("linear_wgrad_finalize");
+}
+
+static int attn_bwd_chunks(int n_windows, int heads) {
+    int G = 1024 / heads;
+    if (G > n_windows) G = n_windows;
+    return G < 1 ? 1 : G;
+}
+
+extern "C" size_t uf_window_attention_bwd_workspace_bytes(int n_windows, int heads) {
+    if (n_windows <= 0 || heads <= 0) return 0;
+    return (size_t)attn_bwd_chunks(n_windows, heads) * heads * 4096 * sizeof(float);
+}
+
+extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask, int n_mask,
+                                       const void* dO, int ldo, void* dq, void* dk, void* dvt, float* dbias, int n_windows, int heads,
+                                       int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(q && k && vt && bias_dense && dO && dq && dk && dvt && dbias && ws, UF_ERR_NULL, "uf_window_attention_bwd: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: dtype %d", (int)dtype);
+    UF_REQUIRE(n_windows > 0 && heads > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: n_windows=%d heads=%d", n_windows, heads);
+    UF_REQUIRE(head_dim == 32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: head_dim %d (32 only so far)", head_dim);
+    UF_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && n_windows % ((H / 8) * (W / 8)) == 0, UF_ERR_SHAPE,
+               "uf_window_attention_bwd: H=%d W=%d n_windows=%d", H, W, n_windows);
+    UF_REQUIRE(shift == 0 || shift == 4, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: shift %d (0 or 4)", shift);
+    UF_REQUIRE(!mask || n_mask > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: mask given with n_mask=%d", n_mask);
+    const int EP = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(ldo >= heads * head_dim && ldo % EP == 0, UF_ERR_ALIGN, "uf_window_attention_bwd: ldo=%d", ldo);
+    const size_t need = uf_window_attention_bwd_workspace_bytes(n_windows, heads);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_window_attention_bwd: workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    const int G = attn_bwd_chunks(n_windows, heads);
+    const int SZ = (int)dtype_size(dtype);
+    const int smem = 4 * 64 * (32 * SZ + 16) + 3 * 32 * (64 * SZ + 16) + 4 * 64 * (64 * SZ + 16);
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "window_attn_bwd_%s %dx%d", dtype == UF_BF16 ? "bf16" : "f32", n_windows, heads);
+    {
+        const double pairs = (double)n_windows * heads;
+        ScopedTimer tm(name, 2.0 * 5 * 64 * 64 * 32 * pairs, pairs * 64 * 32 * 7.0 * SZ, st);
+        if (dtype == UF_BF16) {
+            static bool done[64] = {};
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16>), smem, done, "window_attn_bwd")) return rc;
+            hipLaunchKernelGGL(window_attn_bwd_kernel<bf16>, dim3(heads, G), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
+                               bias_dense, mask, n_mask, (const bf16*)dO, ldo, (bf16*)dq, (bf16*)dk, (bf16*)dvt, (float*)ws, n_windows, heads, H, W, shift);
+        } else {
+            static bool done[64] = {};
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<float>), smem, done, "window_attn_bwd")) return rc;
+            hipLaunchKernelGGL(window_attn_bwd_kernel<float>, dim3(heads, G), dim3(256), smem, st, (const float*)q, (const float*)k, (const float*)vt,
+                               bias_dense, mask, n_mask, (const float*)dO, ldo, (float*)dq, (float*)dk, (float*)dvt, (float*)ws, n_windows, heads, H, W, shift);
+        }
+    }
+    int rc = check_launch("window_attn_bwd");
+    if (rc) return rc;
+    const int nb = heads * 4096;
+    hipLaunchKernelGGL(column_sum_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)ws, G, (size_t)nb, dbias, nb);
+    return check_launch("window_attn_bwd_finalize");
 }

@@ -287,6 +287,30 @@ def linear_wgrad(dy: Tensor, x: Tensor, with_bias: bool = True):
     return dW, db
 
 
+def window_attention_bwd(q: Tensor, k: Tensor, vt: Tensor, bias: Tensor, do: Tensor, H: int, W: int, shift: int = 0,
+                         mask: Optional[Tensor] = None):
+    """Backward of window_attention_core: q (scaled), k (nW*heads,64,hd), vt (nW*heads,hd,64), bias f32 (heads,64,64),
+    do (nW*64, heads*hd) -> (dq, dk, dvt, dbias f32 (heads,64,64) summed over windows).  model.py:494-519."""
+    _dev(q, k, vt, bias, do)
+    dt = uf_dtype(q.dtype)
+    q, k, vt, do = _c(q), _c(k, q.dtype), _c(vt, q.dtype), _c(do, q.dtype)
+    heads = bias.shape[0]
+    hd = q.shape[-1]
+    n_windows = q.shape[0] // heads
+    dq, dk, dvt = torch.empty_like(q), torch.empty_like(k), torch.empty_like(vt)
+    dbias = torch.empty(heads, 64, 64, dtype=torch.float32, device=q.device)
+    m = _c(mask, torch.float32) if mask is not None else None
+    lib = _lib.load()
+    nbytes = lib.uf_window_attention_bwd_workspace_bytes(n_windows, heads)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.uf_window_attention_bwd(_ptr(q), _ptr(k), _ptr(vt), _ptr(_c(bias, torch.float32)), _ptr(m) if m is not None else None,
+                                               m.shape[0] if m is not None else 0, _ptr(do), do.shape[-1], _ptr(dq), _ptr(dk), _ptr(dvt),
+                                               _ptr(dbias), n_windows, heads, hd, H, W, shift, dt, _ptr(ws), nbytes, _stream()),
+                   "uf_window_attention_bwd")
+    return dq, dk, dvt, dbias
+
+
 def dwconv3x3_wgrad(h: Tensor, dc: Tensor):
     """Tap (9,C) and bias (C,) gradients of the depthwise 3x3 from its input h and output gradient dc, both T(B,H,W,C)."""
     _dev(h, dc)
