@@ -126,3 +126,22 @@ def test_window_attention_bwd(dtype, B, H, heads, shift):
         dq2, dk2, dvt2, db2 = ops.window_attention_bwd(flat(q).cuda(), flat(k).cuda(), flat(v).transpose(1, 2).contiguous().cuda(),
                                                        bias.cuda(), do_rows.cuda(), H, H, 0, mask=mask.cuda())
         assert rel(dq2, flat(rdq)) < tol and rel(db2, rdb) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_lewin_block_backward_vs_reference_autograd(golden, dtype):
+    """A whole LeWin block (shifted windows, 2 heads, modulator): forward + backward assembled from the C-ABI kernels
+    (uformer_amd/train.py) against the gradients the REFERENCE's autograd produced (tests/golden/grad_lewin_block.npz)."""
+    import numpy as np
+    from uformer_amd import train
+    gd = golden("grad_lewin_block")
+    t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
+    p = {k[2:]: t(v).cuda() for k, v in gd.items() if k.startswith("p.")}
+    y, dx, grads = train.lewin_block_forward_backward(t(gd["x"]).cuda(), p, "", int(gd["heads"]), 4, t(gd["gy"]).cuda(), dtype)
+    tol = 1e-3 if dtype == torch.float32 else 6e-2
+    assert rel(y, t(gd["y"])) < tol
+    assert rel(dx, t(gd["dx"])) < tol, rel(dx, t(gd["dx"]))
+    ref = {k[2:]: t(v) for k, v in gd.items() if k.startswith("g.")}
+    assert set(grads) == set(ref), sorted(set(grads) ^ set(ref))
+    worst = max((rel(grads[k], r), k) for k, r in ref.items())
+    assert worst[0] < tol, worst

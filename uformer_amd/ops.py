@@ -296,7 +296,7 @@ def window_attention_bwd(q: Tensor, k: Tensor, vt: Tensor, bias: Tensor, do: Ten
     q, k, vt, do = _c(q), _c(k, q.dtype), _c(vt, q.dtype), _c(do, q.dtype)
     heads = bias.shape[0]
     hd = q.shape[-1]
-    n_windows = q.shape[0] // heads
+    n_windows = q.numel() // (heads * 64 * hd)           # q may be (nW*heads, 64, hd) or (nW, heads, 64, hd)
     dq, dk, dvt = torch.empty_like(q), torch.empty_like(k), torch.empty_like(vt)
     dbias = torch.empty(heads, 64, 64, dtype=torch.float32, device=q.device)
     m = _c(mask, torch.float32) if mask is not None else None
