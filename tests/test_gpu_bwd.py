@@ -145,3 +145,37 @@ def test_lewin_block_backward_vs_reference_autograd(golden, dtype):
     assert set(grads) == set(ref), sorted(set(grads) ^ set(ref))
     worst = max((rel(grads[k], r), k) for k, r in ref.items())
     assert worst[0] < tol, worst
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_model_backward_vs_reference_autograd(golden, dtype):
+    """Whole tiny32 model (9 stages, samplers, stem, head, global residual) under the reference's Charbonnier loss: forward +
+    backward assembled from the C-ABI kernels (uformer_amd/train.py) against the gradients the REFERENCE's autograd produced
+    (tests/golden/grad_model_tiny32_128.npz): d loss / d input and all 299 parameter gradients."""
+    import numpy as np
+    from uformer_amd import spec, train
+    gd = golden("grad_model_tiny32_128")
+    t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(1, 128, 128, 1234)
+    target = spec.synth_input(1, 128, 128, 1235)
+    # dL/dy of the Charbonnier loss (losses.py:41-52) at the REFERENCE forward output (= the oracle's, pinned to it): the loss
+    # gradient is sign-like around |y - target| ~ eps, so it must not inherit the bf16 forward error of the path under test
+    y_ref = O.uformer_forward(x, {k: v.cpu() for k, v in sd.items()}, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths,
+                              num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    assert abs(O.charbonnier_loss(y_ref, target).item() - float(gd["loss"])) < 1e-6
+    dy = OB.charbonnier_loss_bwd(y_ref, target)
+    y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype)
+    assert rel(y, y_ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    tol = 2e-3 if dtype == torch.float32 else 1e-1
+    assert rel(dimg, t(gd["dx"])) < tol, rel(dimg, t(gd["dx"]))
+    names = [str(n) for n in gd["param_names"]]
+    assert set(grads) == set(names)
+    worst = (0.0, "")
+    for n, (s_sum, s_abs, s_max) in zip(names, gd["grad_stats"]):
+        e = abs(grads[n].abs().sum().item() - s_abs) / max(s_abs, 1e-12)
+        worst = max(worst, (e, n))
+    assert worst[0] < tol, worst
+    for kname in [k for k in gd if k.startswith("g.")]:
+        assert rel(grads[kname[2:]], t(gd[kname])) < tol, (kname, rel(grads[kname[2:]], t(gd[kname])))
