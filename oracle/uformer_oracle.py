@@ -169,8 +169,9 @@ def leff(x: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
 
 
 def lewin_block(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int,
-                win: int = WIN, mask: Optional[Tensor] = None) -> Tensor:
-    """LeWinTransformerBlock.forward, eval mode (DropPath = identity).  model.py:908-989."""
+                win: int = WIN, mask: Optional[Tensor] = None, drop: Optional[Tensor] = None) -> Tensor:
+    """LeWinTransformerBlock.forward.  model.py:908-989.  ``drop`` = None: eval mode (DropPath = identity); else a (2, B)
+    tensor of per-sample scales bernoulli(keep)/keep for the attention and the LeFF branch (timm DropPath, :986-987)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
     attn_mask = input_attn_mask(mask, H, W, win) if mask is not None else None   # :914-921
@@ -189,9 +190,15 @@ def lewin_block(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift:
     y = window_reverse(aw.reshape(-1, win, win, C), win, H, W)                   # :975-976
     if shift > 0:
         y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))                    # :980
-    x = shortcut + y.reshape(B, L, C)                                            # :986
+    y = y.reshape(B, L, C)
+    if drop is not None:
+        y = y * drop[0].reshape(B, 1, 1)
+    x = shortcut + y                                                             # :986
     z = layer_norm(x, p[prefix + "norm2.weight"], p[prefix + "norm2.bias"])
-    return x + leff(z, p, prefix + "mlp.")                                       # :987
+    m = leff(z, p, prefix + "mlp.")
+    if drop is not None:
+        m = m * drop[1].reshape(B, 1, 1)
+    return x + m                                                                 # :987
 
 
 def downsample(x: Tensor, p: Dict[str, Tensor], prefix: str) -> Tensor:
@@ -258,13 +265,17 @@ def block_shifts(img_size: int, depths: Sequence[int], win: int = WIN) -> List[L
 
 def uformer_forward(x: Tensor, p: Dict[str, Tensor], *, img_size: int, embed_dim: int,
                     depths: Sequence[int], num_heads: Sequence[int], win: int = WIN,
-                    dd_in: int = 3, mask: Optional[Tensor] = None) -> Tensor:
-    """Uformer.forward in eval mode.  model.py:1269-1305.  ``p`` = reference state_dict."""
+                    dd_in: int = 3, mask: Optional[Tensor] = None, drop_scales: Optional[Tensor] = None) -> Tensor:
+    """Uformer.forward.  model.py:1269-1305.  ``p`` = reference state_dict.  ``drop_scales`` = None: eval mode; else the
+    (2 * n_blocks, B) DropPath scales in execution order (two rows per block: attention branch, LeFF branch)."""
     shifts = block_shifts(img_size, depths, win)
+    first = [sum(depths[:s]) for s in range(9)]
 
     def stage(y: Tensor, s: int) -> Tensor:
         for i in range(depths[s]):                                   # model.py:1054-1060
-            y = lewin_block(y, p, f"{STAGES[s]}.blocks.{i}.", num_heads[s], shifts[s][i], win, mask)
+            bi = first[s] + i
+            dr = drop_scales[2 * bi:2 * bi + 2] if drop_scales is not None else None
+            y = lewin_block(y, p, f"{STAGES[s]}.blocks.{i}.", num_heads[s], shifts[s][i], win, mask, dr)
         return y
 
     y = input_proj(x, p)                                             # :1271

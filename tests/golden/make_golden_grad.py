@@ -102,6 +102,54 @@ def main():
     save("grad_model_tiny32_128", loss=loss.detach(), dx=xin.grad, param_names=np.array(names), grad_stats=stats, **full)
     print("loss %.6f  |dx| max %.3e  params %d" % (float(loss), float(xin.grad.abs().max()), len(names)))
 
+    # ---------------- train() mode: DropPath active (model.py:1093-1095 schedule), masks recorded ---------------------------
+    # timm's DropPath scales a residual branch per sample by bernoulli(keep)/keep.  The masks the reference drew are recorded
+    # in call order (two per block: attention branch, then LeFF branch, blocks in execution order) so that the oracle and the
+    # HIP path can replay exactly the same stochastic depth.
+    import timm.models.layers as tl
+    masks = []
+    orig_fwd = tl.DropPath.forward
+
+    def recording_forward(self, x):
+        if self.drop_prob == 0. or not self.training:
+            masks.append(torch.ones(x.shape[0]))
+            return x
+        keep = 1 - self.drop_prob
+        r = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        r.div_(keep)
+        masks.append(r.reshape(-1).clone())
+        return x * r
+
+    tl.DropPath.forward = recording_forward
+    torch.manual_seed(77)
+    mt = ref.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+                     win_size=8, token_projection="linear", token_mlp="leff", modulator=cfg.modulator, dd_in=cfg.dd_in,
+                     drop_path_rate=0.5).train()
+    mt.load_state_dict(sd, strict=True)
+    xin2 = spec.synth_input(2, 128, 128, 4321).requires_grad_(True)
+    target2 = spec.synth_input(2, 128, 128, 4322)
+    out2 = mt(xin2)
+    loss2 = ref_losses.CharbonnierLoss()(out2, target2)
+    loss2.backward()
+    tl.DropPath.forward = orig_fwd
+    # blocks whose rate is 0 hold nn.Identity instead of DropPath (model.py:883): give them rows of ones, so that the
+    # stored array has two rows for EVERY block in execution order
+    full, it = [], iter(masks)
+    for blk in [m_ for m_ in mt.modules() if isinstance(m_, ref.LeWinTransformerBlock)]:
+        for _ in range(2):
+            full.append(next(it) if isinstance(blk.drop_path, tl.DropPath) else torch.ones(xin2.shape[0]))
+    assert next(it, None) is None
+    masks = full
+    stats2 = np.stack([[float(p_.grad.sum()), float(p_.grad.abs().sum()), float(p_.grad.abs().max())] for _, p_ in mt.named_parameters()])
+    dp_rates = [float(m.drop_prob) for m in mt.modules() if isinstance(m, tl.DropPath)]
+    save("grad_model_tiny32_droppath", loss=loss2.detach(), y=out2.detach(), dx=xin2.grad, masks=torch.stack(masks), drop_rates=np.array(dp_rates),
+         param_names=np.array([k for k, _ in mt.named_parameters()]), grad_stats=stats2,
+         **{"g." + k: p_.grad for k, p_ in mt.named_parameters() if k in (
+             "encoderlayer_0.blocks.0.attn.qkv.to_q.weight", "conv.blocks.0.mlp.linear1.0.bias", "decoderlayer_3.blocks.0.modulator.weight",
+             "decoderlayer_3.blocks.0.mlp.linear2.0.weight", "dowsample_0.conv.0.weight", "input_proj.proj.0.weight")})
+    print("train-mode loss %.6f  masks %s  dropped branches %d of %d" % (float(loss2), tuple(torch.stack(masks).shape),
+          int((torch.stack(masks) == 0).sum()), torch.stack(masks).numel()))
+
 
 if __name__ == "__main__":
     main()

@@ -229,3 +229,28 @@ def test_explicit_backward_per_op(golden):
     x, gy, rdx, p, rg = op("ln")
     dx, dw, db = OB.layer_norm_bwd(x, p["weight"], gy)
     check("ln", dx, {"weight": dw, "bias": db}, rdx, rg)
+
+
+def test_train_mode_droppath_forward_and_backward(golden):
+    """train() mode: the oracle with the DropPath masks the reference drew (recorded in call order) reproduces the reference's
+    stochastic-depth forward and, through autograd, its gradients."""
+    g = golden("grad_model_tiny32_droppath")
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(2, 128, 128, 4321).requires_grad_(True)
+    target = spec.synth_input(2, 128, 128, 4322)
+    masks = t(g["masks"])
+    assert masks.shape == (2 * sum(cfg.depths), 2) and (masks == 0).any()
+    y = O.uformer_forward(x, sd, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads,
+                          dd_in=cfg.dd_in, drop_scales=masks)
+    assert (y - t(g["y"])).abs().max() < TOL
+    loss = O.charbonnier_loss(y, target)
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    loss.backward()
+    assert _rel(x.grad, t(g["dx"])) < GRAD_RTOL
+    for n, (s_sum, s_abs, s_max) in zip([str(n) for n in g["param_names"]], g["grad_stats"]):
+        gr = sd[n].grad
+        val = 0.0 if gr is None else gr.abs().sum().item()            # a block whose two branches were dropped for both samples has no gradient
+        assert abs(val - s_abs) <= 5e-4 * s_abs + 1e-9, n
+    for k, r in params(g, "g.").items():
+        assert _rel(sd[k].grad, r) < GRAD_RTOL, k
