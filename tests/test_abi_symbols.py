@@ -54,7 +54,7 @@ def test_cpu_tensors_raise_no_fallback():
     m = model.get_arch("Uformer_T", 128).eval()
     with pytest.raises(UformerHipError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 128, 128))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(UformerHipError, match="no CPU fallback"):      # the training path is HIP-only as well
         m.train()(torch.zeros(1, 3, 128, 128))
 
 

@@ -179,3 +179,44 @@ def test_model_backward_vs_reference_autograd(golden, dtype):
     assert worst[0] < tol, worst
     for kname in [k for k in gd if k.startswith("g.")]:
         assert rel(grads[kname[2:]], t(gd[kname])) < tol, (kname, rel(grads[kname[2:]], t(gd[kname])))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
+    """The nn.Module boundary in train() mode: ``loss.backward()`` through uformer_amd.model.Uformer (UformerFunction over
+    the C-ABI kernels) with the stochastic-depth masks the reference drew, against the reference's own train-mode forward
+    and gradients (tests/golden/grad_model_tiny32_droppath.npz; train/train_denoise.py:180-184 is this sequence)."""
+    import numpy as np
+    from uformer_amd import model, spec
+    gd = golden("grad_model_tiny32_droppath")
+    t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
+    cfg = spec.arch_config("tiny32", img_size=128)
+    m = model.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+                      modulator=cfg.modulator, dd_in=cfg.dd_in, drop_path_rate=0.5, compute_dtype=dtype)
+    m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
+    m = m.cuda().train()
+    assert np.allclose(m.drop_path_rates(), [0.0] + list(gd["drop_rates"]) + [0.0], atol=1e-6)      # schedule of model.py:1093-1095
+    m._drop_scales_override = t(gd["masks"]).cuda()
+    x = spec.synth_input(2, 128, 128, 4321).cuda().requires_grad_(True)
+    target = spec.synth_input(2, 128, 128, 4322).cuda()
+    y = m(x)
+    d = y - target
+    loss = torch.mean(torch.sqrt(d * d + 1e-6))                             # CharbonnierLoss, eps = 1e-3 (losses.py:41-52)
+    tolf = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(y.detach(), t(gd["y"])) < tolf and abs(loss.item() - float(gd["loss"])) < (1e-5 if dtype == torch.float32 else 2e-3)
+    if dtype == torch.bfloat16:      # the sign-like loss gradient must not inherit the bf16 forward error: feed the reference's
+        dref = t(gd["y"]).cuda() - target
+        y.backward(dref / torch.sqrt(dref * dref + 1e-6) / dref.numel())
+    else:
+        loss.backward()
+    tol = 2e-3 if dtype == torch.float32 else 1e-1
+    assert rel(x.grad, t(gd["dx"])) < tol
+    params = dict(m.named_parameters())
+    worst = (0.0, "")
+    for n, (s_sum, s_abs, s_max) in zip([str(n) for n in gd["param_names"]], gd["grad_stats"]):
+        gr = params[n].grad
+        val = 0.0 if gr is None else gr.abs().sum().item()
+        worst = max(worst, (abs(val - s_abs) / s_abs if s_abs > 0 else val, n))
+    assert worst[0] < tol, worst
+    for kname in [k for k in gd if k.startswith("g.")]:
+        assert rel(params[kname[2:]].grad, t(gd[kname])) < tol, kname

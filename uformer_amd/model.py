@@ -294,7 +294,7 @@ class LeWinTransformerBlock(nn.Module):
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, compute_dtype=torch.float32) -> Tensor:
         """(B, L, C) -> (B, L, C); eval semantics (DropPath is identity)."""
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training backward (SURVEY.md section 8 row a15) is not built yet; use eval()/no_grad")
+            raise NotImplementedError("block-level autograd is not wired: train through Uformer.forward (uformer_amd/train.py) or use eval()/no_grad")
         B, L, Cc = x.shape
         H = W = int(math.sqrt(L))
         if not x.is_cuda:
@@ -457,14 +457,15 @@ class Uformer(nn.Module):
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training backward (SURVEY.md section 8 row a15) is not built yet; call .eval() "
-                                      "or run under torch.no_grad()")
         if not x.is_cuda:
             raise UformerHipError("uformer_amd.Uformer runs on an MI355X only; there is no CPU fallback "
                                   "(the CPU oracle lives in oracle/ and is test infrastructure)")
         if x.dim() != 4 or x.shape[1] != self.dd_in:
             raise UformerHipError(f"expected (B,{self.dd_in},H,W) input, got {tuple(x.shape)}")
+        if self.training and torch.is_grad_enabled():
+            if mask is not None:
+                raise NotImplementedError("the mask argument is not supported by the training path (no reference script passes it)")
+            return self._forward_train(x)
         if mask is not None:
             return self._forward_blockwise(x, mask)
         B, _, H, W = x.shape
@@ -482,6 +483,24 @@ class Uformer(nn.Module):
             _lib.check(lib.uf_uformer_fwd(pk.desc, xin.data_ptr(), out.data_ptr(), B, H, W, dt, self._ws.data_ptr(),
                                           self._ws.numel(), torch.cuda.current_stream().cuda_stream), "uf_uformer_fwd")
         return out.to(x.dtype)
+
+    def drop_path_rates(self):
+        """Per-block stochastic-depth rates in execution order (model.py:1093-1095)."""
+        from .spec import STAGES
+        return [float(blk.drop_path_rate) for name in STAGES for blk in getattr(self, name).blocks]
+
+    def _forward_train(self, x: Tensor) -> Tensor:
+        """train() with grad enabled: the op-by-op tape of uformer_amd/train.py behind torch.autograd (the fused inference
+        kernels keep no activations).  DropPath masks are drawn here, per block and branch, as timm's DropPath does
+        (train/train_denoise.py:181-184 then calls backward on the loss)."""
+        from . import train
+        sd = self.state_dict(keep_vars=True)
+        names, params = list(sd.keys()), list(sd.values())
+        rates = self.drop_path_rates()
+        drop = getattr(self, "_drop_scales_override", None)
+        if drop is None and any(r > 0 for r in rates):
+            drop = train.sample_drop_scales(rates, x.shape[0], x.device)
+        return train.UformerFunction.apply(x, self.cfg, self.compute_dtype, drop, names, *params)
 
     def _forward_blockwise(self, x: Tensor, mask: Optional[Tensor]) -> Tensor:
         """Module-by-module path (used when the rarely-used ``mask`` argument is given):

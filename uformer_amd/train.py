@@ -13,7 +13,7 @@ Eval-mode semantics (DropPath = identity), as the gradient fixtures.  model.py:9
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn.functional as F
@@ -39,8 +39,10 @@ def _input_grad(dy: Tensor, w: Tensor) -> Tensor:
 # ------------------------------------------------------------------------------------------------------------------
 # LeWin block (model.py:908-989)
 # ------------------------------------------------------------------------------------------------------------------
-def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype: torch.dtype) -> Tuple[Tensor, Saved]:
-    """x: (B, L, C) f32 on the GPU -> (y, saved).  Op-by-op forward that keeps what the backward reads."""
+def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype: torch.dtype,
+                        drop: Optional[Tensor] = None) -> Tuple[Tensor, Saved]:
+    """x: (B, L, C) f32 on the GPU -> (y, saved).  Op-by-op forward that keeps what the backward reads.
+    ``drop``: None (eval) or (2, B) per-sample DropPath scales bernoulli(keep)/keep of the two residual branches (model.py:986-987)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
     M, hd = B * L, C // heads
@@ -57,14 +59,18 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     q, k, vt = ops.qkv(xn, wqkv, bqkv, heads)                                # window rows; q already scaled
     o = ops.window_attention_core(q, k, vt, bias, H=H, W=W, shift=shift)     # (M, C) window rows
     yw = ops.linear(o, wp, f("attn.proj.bias"))
-    x1 = x2 + ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float()
+    s1 = drop[0].float().repeat_interleave(L).reshape(M, 1) if drop is not None else None      # per-token copy of the per-sample scale
+    s2 = drop[1].float().repeat_interleave(L).reshape(M, 1) if drop is not None else None
+    br1 = ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float()
+    x1 = x2 + (br1 * s1 if s1 is not None else br1)
     z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
     a1 = ops.linear(z, w1, f("mlp.linear1.0.bias"))                          # pre-activation, kept for GELU'
     h1 = ops.linear(z, w1, f("mlp.linear1.0.bias"), act=1).reshape(B, H, W, 4 * C)
     c = ops.dwconv3x3(h1, w9, f("mlp.dwconv.0.bias"), gelu=False)            # pre-activation of the second GELU
     g2 = ops.dwconv3x3(h1, w9, f("mlp.dwconv.0.bias"), gelu=True).reshape(M, 4 * C)
-    y = x1 + ops.linear(g2, w2, f("mlp.linear2.0.bias")).float()
-    saved = dict(p=p, prefix=prefix, heads=heads, shift=shift, T=T, shape=(B, L, C), x2=x2, xn=xn, q=q, k=k, vt=vt, o=o, x1=x1, z=z, a1=a1,
+    br2 = ops.linear(g2, w2, f("mlp.linear2.0.bias")).float()
+    y = x1 + (br2 * s2 if s2 is not None else br2)
+    saved = dict(s1=s1, s2=s2, p=p, prefix=prefix, heads=heads, shift=shift, T=T, shape=(B, L, C), x2=x2, xn=xn, q=q, k=k, vt=vt, o=o, x1=x1, z=z, a1=a1,
                  h1=h1, c=c, g2=g2, wqkv=wqkv, wp=wp, w1=w1, w2=w2, w9=w9, bias=bias, mod=mod is not None)
     return y.reshape(B, L, C), saved
 
@@ -77,7 +83,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     M, hd = B * L, C // heads
     f = lambda k: p[prefix + k]                                             # noqa: E731
     g: Grads = {}
-    dyT = dy.reshape(M, C).to(T).contiguous()
+    dyf = dy.reshape(M, C).float()
+    dyT = (dyf * sv["s2"] if sv["s2"] is not None else dyf).to(T).contiguous()      # gradient entering the (scaled) LeFF branch
     # LeFF: linear2 -> GELU -> depthwise -> GELU -> linear1                                   (model.py:666-685)
     g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = ops.linear_wgrad(dyT, sv["g2"])
     dg2 = _input_grad(dyT, sv["w2"])
@@ -91,7 +98,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd(sv["x1"], f("norm2.weight"), dz)
     dx1 = dx1 + dy.reshape(M, C).float()
     # attention half: proj -> attention -> qkv -> (+modulator) -> partition/roll -> LN1              (model.py:951-986)
-    dyw = ops.window_partition(dx1.reshape(B, H, W, C), 8, shift).reshape(M, C).to(T)
+    dbr1 = dx1 * sv["s1"] if sv["s1"] is not None else dx1                          # gradient entering the (scaled) attention branch
+    dyw = ops.window_partition(dbr1.reshape(B, H, W, C), 8, shift).reshape(M, C).to(T)
     g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = ops.linear_wgrad(dyw, sv["o"])
     do = _input_grad(dyw, sv["wp"])
     dq, dk, dvt, dbias = ops.window_attention_bwd(sv["q"], sv["k"], sv["vt"], sv["bias"], do, H, W, shift)
@@ -156,77 +164,136 @@ def _img2tok(y: Tensor) -> Tensor:
     return y.flatten(2).transpose(1, 2).reshape(-1, C).contiguous()
 
 
-def uformer_forward_backward(img: Tensor, sd: Dict[str, Tensor], dy: Tensor, *, cfg, dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor, Grads]:
-    """Whole-model forward + backward (model.py:1269-1305), eval-mode semantics.  img, dy: (B,3,H,W) f32 on the GPU; sd: the
-    reference state_dict on the GPU; cfg: uformer_amd.spec.UformerConfig.  Returns (y, d img, parameter gradients)."""
-    from .spec import STAGES
-    T = dtype
-    B, _, H, W = img.shape
-    shifts = cfg.block_shifts()
-    res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
-    saved_blocks: List[List[Saved]] = [[] for _ in range(9)]
+class UformerTape:
+    """One forward of the whole model (model.py:1269-1305) that keeps what the reverse sweep reads, and that sweep.
+    ``drop_scales``: None (eval semantics) or a (2 * n_blocks, B) tensor of DropPath scales in execution order."""
 
-    def stage_fwd(s: int, t: Tensor) -> Tensor:                                 # t: (M, C) f32 token rows
-        C = t.shape[1]
-        t = t.reshape(B, res[s] * res[s], C)
-        for i in range(cfg.depths[s]):
-            t, sv = lewin_block_forward(t, sd, f"{STAGES[s]}.blocks.{i}.", cfg.num_heads[s], shifts[s][i], T)
-            saved_blocks[s].append(sv)
-        return t.reshape(-1, C)
+    def __init__(self, sd: Dict[str, Tensor], cfg, dtype: torch.dtype = torch.float32, drop_scales: Optional[Tensor] = None):
+        self.sd, self.cfg, self.T, self.drop = sd, cfg, dtype, drop_scales
 
-    def stage_bwd(s: int, d: Tensor, g: Grads) -> Tensor:
-        C = d.shape[1]
-        d = d.reshape(B, res[s] * res[s], C)
-        for sv in reversed(saved_blocks[s]):
-            d, gb = lewin_block_backward(sv, d)
-            g.update(gb)
-        return d.reshape(-1, C)
+    def forward(self, img: Tensor) -> Tensor:
+        from .spec import STAGES
+        sd, cfg, T = self.sd, self.cfg, self.T
+        B, _, H, W = img.shape
+        self.B, self.H = B, H
+        shifts = cfg.block_shifts()
+        res = self.res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
+        first = [sum(cfg.depths[:s]) for s in range(9)]
+        self.saved_blocks: List[List[Saved]] = [[] for _ in range(9)]
 
-    # ---- forward with the inference kernels of the samplers / stem / head, keeping their inputs
-    t = ops.input_proj(img, packing.pack_input_proj(sd["input_proj.proj.0.weight"]), sd["input_proj.proj.0.bias"])
-    stem_out = t
-    skips, down_in, up_in = [], [], []
-    for s in range(4):
-        t = stage_fwd(s, t)
-        skips.append(t)
-        down_in.append(t)
-        t = ops.downsample(t, packing.pack_downsample(sd[f"dowsample_{s}.conv.0.weight"], T), sd[f"dowsample_{s}.conv.0.bias"], B, res[s], res[s])
-    t = stage_fwd(4, t)
-    for k in range(4):
-        up_in.append(t)
-        up = ops.upsample(t, packing.pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], T), sd[f"upsample_{k}.deconv.0.bias"], B, res[4 + k], res[4 + k])
-        t = stage_fwd(5 + k, torch.cat([up, skips[3 - k]], 1))                   # model.py:1288
-    head_in = t
-    y = ops.output_proj(t, packing.pack_output_proj(sd["output_proj.proj.0.weight"]), sd["output_proj.proj.0.bias"], B, H, W,
-                        img if cfg.dd_in == 3 else None)
+        def stage_fwd(s: int, t: Tensor) -> Tensor:                             # t: (M, C) f32 token rows
+            C = t.shape[1]
+            t = t.reshape(B, res[s] * res[s], C)
+            for i in range(cfg.depths[s]):
+                bi = first[s] + i
+                dr = self.drop[2 * bi:2 * bi + 2] if self.drop is not None else None
+                t, sv = lewin_block_forward(t, sd, f"{STAGES[s]}.blocks.{i}.", cfg.num_heads[s], shifts[s][i], T, dr)
+                self.saved_blocks[s].append(sv)
+            return t.reshape(-1, C)
 
-    # ---- reverse sweep
-    g: Grads = {}
-    dy_rows = dy.permute(0, 2, 3, 1).reshape(B * H * W, 3)
-    dxi, g["output_proj.proj.0.weight"], g["output_proj.proj.0.bias"] = _conv_backward(_tok2img(head_in, B), sd["output_proj.proj.0.weight"], dy_rows, 1, 1, T)
-    d = _img2tok(dxi)
-    dskip: List[Tensor] = [None] * 4
-    for k in reversed(range(4)):
-        d = stage_bwd(5 + k, d, g)
-        Cs = skips[3 - k].shape[1]
-        cup = d.shape[1] - Cs
-        dskip[3 - k] = d[:, cup:]
-        # ConvTranspose2d k2 s2 = four independent 1x1 GEMMs: gather the 2x2 output pixels of every input pixel into one row
-        r = res[4 + k]
-        w = sd[f"upsample_{k}.deconv.0.weight"]                                    # (Cin, Cout, 2, 2)
-        d4 = d[:, :cup].reshape(B, r, 2, r, 2, cup).permute(0, 1, 3, 2, 4, 5).reshape(B * r * r, 4 * cup).to(T).contiguous()
-        wpk = packing.pack_upsample(w, T)                                          # (4*Cout, Cin), n = (dy*2+dx)*Cout + co
-        dWp, dbp = ops.linear_wgrad(d4, up_in[k].to(T))
-        g[f"upsample_{k}.deconv.0.weight"] = dWp.reshape(2, 2, cup, w.shape[0]).permute(3, 2, 0, 1).contiguous()
-        g[f"upsample_{k}.deconv.0.bias"] = dbp.reshape(4, cup).sum(0)
-        d = _input_grad(d4, wpk).float()
-    d = stage_bwd(4, d, g)
-    for s in reversed(range(4)):
-        dxi, g[f"dowsample_{s}.conv.0.weight"], g[f"dowsample_{s}.conv.0.bias"] = _conv_backward(
-            _tok2img(down_in[s], B), sd[f"dowsample_{s}.conv.0.weight"], d, 2, 1, T)
-        d = stage_bwd(s, _img2tok(dxi) + dskip[s], g)
-    dpre = d * torch.where(stem_out >= 0, torch.ones_like(stem_out), torch.full_like(stem_out, 0.01))     # LeakyReLU(0.01), model.py:786
-    dimg, g["input_proj.proj.0.weight"], g["input_proj.proj.0.bias"] = _conv_backward(img.float(), sd["input_proj.proj.0.weight"], dpre, 1, 1, T)
-    if cfg.dd_in == 3:
-        dimg = dimg + dy                                                          # global residual, model.py:1305
+        # the samplers / stem / head run their inference kernels; their inputs are kept
+        self.img = img
+        t = ops.input_proj(img, packing.pack_input_proj(sd["input_proj.proj.0.weight"]), sd["input_proj.proj.0.bias"])
+        self.stem_out = t
+        self.skips, self.down_in, self.up_in = [], [], []
+        for s in range(4):
+            t = stage_fwd(s, t)
+            self.skips.append(t)
+            self.down_in.append(t)
+            t = ops.downsample(t, packing.pack_downsample(sd[f"dowsample_{s}.conv.0.weight"], T), sd[f"dowsample_{s}.conv.0.bias"], B, res[s], res[s])
+        t = stage_fwd(4, t)
+        for k in range(4):
+            self.up_in.append(t)
+            up = ops.upsample(t, packing.pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], T), sd[f"upsample_{k}.deconv.0.bias"], B, res[4 + k], res[4 + k])
+            t = stage_fwd(5 + k, torch.cat([up, self.skips[3 - k]], 1))           # model.py:1288
+        self.head_in = t
+        return ops.output_proj(t, packing.pack_output_proj(sd["output_proj.proj.0.weight"]), sd["output_proj.proj.0.bias"], B, H, W,
+                               img if cfg.dd_in == 3 else None)
+
+    def backward(self, dy: Tensor) -> Tuple[Tensor, Grads]:
+        sd, cfg, T, B, H, res = self.sd, self.cfg, self.T, self.B, self.H, self.res
+
+        def stage_bwd(s: int, d: Tensor, g: Grads) -> Tensor:
+            C = d.shape[1]
+            d = d.reshape(B, res[s] * res[s], C)
+            for sv in reversed(self.saved_blocks[s]):
+                d, gb = lewin_block_backward(sv, d)
+                g.update(gb)
+            return d.reshape(-1, C)
+
+        g: Grads = {}
+        dy = dy.float()
+        dy_rows = dy.permute(0, 2, 3, 1).reshape(B * H * H, 3)
+        dxi, g["output_proj.proj.0.weight"], g["output_proj.proj.0.bias"] = _conv_backward(_tok2img(self.head_in, B), sd["output_proj.proj.0.weight"], dy_rows, 1, 1, T)
+        d = _img2tok(dxi)
+        dskip: List[Tensor] = [None] * 4
+        for k in reversed(range(4)):
+            d = stage_bwd(5 + k, d, g)
+            Cs = self.skips[3 - k].shape[1]
+            cup = d.shape[1] - Cs
+            dskip[3 - k] = d[:, cup:]
+            # ConvTranspose2d k2 s2 = four independent 1x1 GEMMs: gather the 2x2 output pixels of every input pixel into one row
+            r = res[4 + k]
+            w = sd[f"upsample_{k}.deconv.0.weight"]                                # (Cin, Cout, 2, 2)
+            d4 = d[:, :cup].reshape(B, r, 2, r, 2, cup).permute(0, 1, 3, 2, 4, 5).reshape(B * r * r, 4 * cup).to(T).contiguous()
+            wpk = packing.pack_upsample(w, T)                                      # (4*Cout, Cin), n = (dy*2+dx)*Cout + co
+            dWp, dbp = ops.linear_wgrad(d4, self.up_in[k].to(T))
+            g[f"upsample_{k}.deconv.0.weight"] = dWp.reshape(2, 2, cup, w.shape[0]).permute(3, 2, 0, 1).contiguous()
+            g[f"upsample_{k}.deconv.0.bias"] = dbp.reshape(4, cup).sum(0)
+            d = _input_grad(d4, wpk).float()
+        d = stage_bwd(4, d, g)
+        for s in reversed(range(4)):
+            dxi, g[f"dowsample_{s}.conv.0.weight"], g[f"dowsample_{s}.conv.0.bias"] = _conv_backward(
+                _tok2img(self.down_in[s], B), sd[f"dowsample_{s}.conv.0.weight"], d, 2, 1, T)
+            d = stage_bwd(s, _img2tok(dxi) + dskip[s], g)
+        so = self.stem_out
+        dpre = d * torch.where(so >= 0, torch.ones_like(so), torch.full_like(so, 0.01))     # LeakyReLU(0.01), model.py:786
+        dimg, g["input_proj.proj.0.weight"], g["input_proj.proj.0.bias"] = _conv_backward(self.img.float(), sd["input_proj.proj.0.weight"], dpre, 1, 1, T)
+        if cfg.dd_in == 3:
+            dimg = dimg + dy                                                      # global residual, model.py:1305
+        return dimg, g
+
+
+def uformer_forward_backward(img: Tensor, sd: Dict[str, Tensor], dy: Tensor, *, cfg, dtype: torch.dtype = torch.float32,
+                             drop_scales: Optional[Tensor] = None) -> Tuple[Tensor, Tensor, Grads]:
+    """Whole-model forward + backward.  img, dy: (B,3,H,W) f32 on the GPU; sd: the reference state_dict on the GPU; cfg:
+    uformer_amd.spec.UformerConfig.  Returns (y, d img, parameter gradients keyed like named_parameters())."""
+    tape = UformerTape(sd, cfg, dtype, drop_scales)
+    y = tape.forward(img)
+    dimg, g = tape.backward(dy)
     return y, dimg, g
+
+
+class UformerFunction(torch.autograd.Function):
+    """torch.autograd entry: ``y = UformerFunction.apply(img, cfg, dtype, drop_scales, names, *params)``; backward() hands the
+    parameter gradients of the tape to autograd in the order of ``names`` (buffers such as relative_position_index get None)."""
+
+    @staticmethod
+    def forward(ctx, img, cfg, dtype, drop_scales, names, *params):
+        sd = {n: p.detach() for n, p in zip(names, params)}
+        tape = UformerTape(sd, cfg, dtype, drop_scales)
+        y = tape.forward(img.detach().float().contiguous())
+        ctx.tape, ctx.names = tape, names
+        ctx.img_needs_grad = img.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dimg, g = ctx.tape.backward(dy.contiguous())
+        ctx.tape = None                                                           # free the saved activations
+        grads = tuple(g.get(n) for n in ctx.names)
+        return (dimg if ctx.img_needs_grad else None, None, None, None, None) + grads
+
+
+def sample_drop_scales(rates: Sequence[float], B: int, device, generator: Optional[torch.Generator] = None) -> Tensor:
+    """timm DropPath for every block in execution order: two rows (attention branch, LeFF branch) of per-sample scales
+    bernoulli(1 - rate) / (1 - rate); rate 0 -> ones.  (model.py:883, :986-987; schedule :1093-1095.)"""
+    rows = []
+    for r in rates:
+        for _ in range(2):
+            if r <= 0.0:
+                rows.append(torch.ones(B, device=device))
+            else:
+                keep = 1.0 - r
+                rows.append(torch.bernoulli(torch.full((B,), keep, device=device), generator=generator) / keep)
+    return torch.stack(rows)
