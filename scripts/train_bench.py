@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""First measurement of BASELINE configs[2] (Uformer-B 256x256 training step: forward + backward + AdamW) on the op-by-op
+backward of uformer_amd/train.py.  Not the contract bench (bench.py measures the inference metric); prints one JSON line.
+
+    python scripts/train_bench.py --batch 32 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from uformer_amd import model as um  # noqa: E402
+from uformer_amd import spec  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--arch", default="Uformer_B")
+    ap.add_argument("--img", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    a = ap.parse_args()
+    cfg = spec.arch_config(a.arch, img_size=a.img)
+    m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
+                   dd_in=cfg.dd_in, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+    m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
+    m = m.cuda().train()
+    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77
+    x = spec.synth_input(a.batch, a.img, a.img, 1234).cuda()
+    target = spec.synth_input(a.batch, a.img, a.img, 1235).cuda()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        d = m(x) - target
+        loss = torch.mean(torch.sqrt(d * d + 1e-6))                                  # CharbonnierLoss (losses.py:41-52)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"metric": "training images/sec (fwd+bwd+AdamW, op-by-op backward)", "value": a.batch / dt, "ms_per_step": dt * 1e3,
+                      "batch": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss": float(loss),
+                      "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+
+
+if __name__ == "__main__":
+    main()
