@@ -58,3 +58,55 @@ def test_two_rank_sharded_inference_matches_single_process():
         assert p.exitcode == 0
     assert t == 2.0 and n == 3.0
     assert err < 1e-5
+
+
+def _train_worker(rank, world, port, q):
+    """Data-parallel training exchange: each rank differentiates the loss of ITS shard (oracle autograd stands in for the HIP
+    backward), GradientAllReduce averages; with the per-rank loss weighted by its shard size the result must equal the
+    single-process gradient of the whole batch."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import uformer_oracle as O
+    from uformer_amd import dist as ud
+    from uformer_amd import spec
+    torch.set_num_threads(2)
+    ud.init_process_group("gloo")
+    cfg = spec.arch_config("tiny", 128)
+    kw = dict(img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
+    gb = 2
+    x, tgt = spec.synth_input(gb, 128, 128, 6), spec.synth_input(gb, 128, 128, 7)
+
+    def grads_of(xs, ts, weight):
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 5).items()}
+        (O.charbonnier_loss(O.uformer_forward(xs, sd, **kw), ts) * weight).backward()
+        return [v for v in sd.values() if v.is_floating_point()]
+
+    a, b = ud.shard_batch(gb, rank, world)
+    params = grads_of(x[a:b], tgt[a:b], world * (b - a) / gb)       # mean over ranks of (world * n_r / N) * L_r == L of the whole batch
+    if rank == 1:
+        params[3].grad = None                                          # a gradient DropPath removed on one rank only
+    red = ud.GradientAllReduce(params, bucket_bytes=256 << 10)
+    assert len(red.buckets) > 3 and sum(len(bk) for bk in red.buckets) == len(params)
+    red()
+    if rank == 0:
+        ref = grads_of(x, tgt, 1.0)
+        keep = grads_of(x[a:b], tgt[a:b], world * (b - a) / gb)[3].grad / world      # rank 1 contributed zeros to this one
+        err = max(float((p.grad - r.grad).abs().max() / r.grad.abs().max()) for i, (p, r) in enumerate(zip(params, ref)) if i != 3)
+        err3 = float((params[3].grad - keep).abs().max() / keep.abs().max())
+        q.put((err, err3, len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, err3, nb = q.get(timeout=400)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-4 and err3 < 1e-5 and nb > 3

@@ -72,3 +72,70 @@ def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([bufs[r][: b - a] for r, (a, b) in enumerate(sizes)], 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training: the one exchange step of data parallelism -- average the gradients over the ranks.
+# Replaces nn.DataParallel's gather-on-GPU-0 (train/train_denoise.py:83) by a bucketed all-reduce over RCCL (backend
+# "nccl" on ROCm) / gloo.
+# ---------------------------------------------------------------------------------------------------------------------
+class GradientAllReduce:
+    """Bucketed mean of ``param.grad`` over all ranks.
+
+    Parameters are laid out in REVERSE registration order (the order the backward sweep finishes them: decoder first) into
+    flat f32 buckets of about ``bucket_bytes`` (25 MB: large enough to run at xGMI link rate, small enough that several are
+    in flight); every bucket is one asynchronous all-reduce.  Gradients that are None on this rank (a block whose two
+    branches DropPath dropped for every local sample) take part as zeros -- the collective must be the same on all ranks.
+    203.5 MB of fp32 gradients for Uformer-B = 9 buckets."""
+
+    def __init__(self, params, bucket_bytes: int = 25 << 20):
+        self.params = [p for p in params if p.requires_grad][::-1]
+        self.buckets = []            # lists of parameter indices
+        cur, size = [], 0
+        for i, p in enumerate(self.params):
+            n = p.numel() * 4
+            if cur and size + n > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(i)
+            size += n
+        if cur:
+            self.buckets.append(cur)
+        self._flat = None
+
+    def _buffers(self, device):
+        if self._flat is None or self._flat[0].device != device:
+            self._flat = [torch.empty(sum(self.params[i].numel() for i in b), dtype=torch.float32, device=device) for b in self.buckets]
+        return self._flat
+
+    def __call__(self) -> None:
+        """All-reduce and average in place; a no-op in a single-process run."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        flats = self._buffers(self.params[0].device)
+        works = []
+        for b, flat in zip(self.buckets, flats):
+            off = 0
+            for i in b:
+                p = self.params[i]
+                n = p.numel()
+                if p.grad is None:
+                    flat[off:off + n].zero_()
+                else:
+                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))     # later buckets pack while this one flies
+        for b, flat, w in zip(self.buckets, flats, works):
+            w.wait()
+            flat.div_(world)
+            off = 0
+            for i in b:
+                p = self.params[i]
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
