@@ -3,6 +3,9 @@
 backward of uformer_amd/train.py.  Not the contract bench (bench.py measures the inference metric); prints one JSON line.
 
     python scripts/train_bench.py --batch 32 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/train_bench.py --batch 32
+        (BASELINE configs[3]: 32 images per GPU, gradients averaged by uformer_amd.dist.GradientAllReduce over RCCL;
+         not yet run on a multi-GPU box)
 """
 import argparse
 import json
@@ -13,6 +16,7 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+from uformer_amd import dist as ud  # noqa: E402
 from uformer_amd import model as um  # noqa: E402
 from uformer_amd import spec  # noqa: E402
 
@@ -26,34 +30,44 @@ def main():
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     a = ap.parse_args()
+    rank, local_rank, world = ud.init_process_group("nccl")
+    torch.cuda.set_device(local_rank)
+    torch.manual_seed(1234 + rank)                                                 # DropPath masks differ per rank (train/train_denoise.py:60-63 seeds 1234)
     cfg = spec.arch_config(a.arch, img_size=a.img)
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
                    dd_in=cfg.dd_in, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
     m = m.cuda().train()
     opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77
-    x = spec.synth_input(a.batch, a.img, a.img, 1234).cuda()
-    target = spec.synth_input(a.batch, a.img, a.img, 1235).cuda()
+    x = spec.synth_input(a.batch, a.img, a.img, 1234 + 2 * rank).cuda()            # per-GPU batch (weak scaling)
+    target = spec.synth_input(a.batch, a.img, a.img, 1235 + 2 * rank).cuda()
+    reduce_grads = ud.GradientAllReduce(list(m.parameters()))
 
     def step():
         opt.zero_grad(set_to_none=True)
         d = m(x) - target
         loss = torch.mean(torch.sqrt(d * d + 1e-6))                                  # CharbonnierLoss (losses.py:41-52)
         loss.backward()
+        reduce_grads()                                                               # no-op on one GPU
         opt.step()
         return loss
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
+    ud.barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"metric": "training images/sec (fwd+bwd+AdamW, op-by-op backward)", "value": a.batch / dt, "ms_per_step": dt * 1e3,
-                      "batch": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss": float(loss),
-                      "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    ud.barrier()
+    dt = ud.max_over_ranks(time.perf_counter() - t0, "cuda") / a.steps
+    if rank == 0:
+        print(json.dumps({"metric": "training images/sec (fwd+bwd+AdamW, op-by-op backward)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3,
+                          "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss": float(loss),
+                          "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
