@@ -205,6 +205,8 @@ int uf_output_proj_fwd(const float* x, int ld_x, const float* w, const float* bi
  * (bit-reproducible, no atomics). -------------------------------------------------------------------------- */
 /* dx = dy * GELU'(a), erf form (nn.GELU, model.py:657-660).  a, dy, dx: T[n], n multiple of 16 bytes / sizeof(T) */
 int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype dtype, void* stream);
+/* y = GELU(a) as a separate pass, for a training forward that keeps the pre-activation (same flavour as the fused epilogues) */
+int uf_gelu_fwd(const void* a, void* y, long long n, uf_dtype dtype, void* stream);
 /* nn.LayerNorm(C) backward over rows of the f32 stream: dx f32[rows][ld_dx]; dgamma, dbeta f32[C] are OVERWRITTEN
  * with the sums over all rows.  C in {16,32,64,128,256,512,1024}. */
 size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);

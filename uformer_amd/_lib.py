@@ -61,6 +61,7 @@ SIGNATURES = {
     "uf_dwconv3x3_gelu_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "uf_dwconv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "uf_gelu_bwd": (I, [P, P, P, C.c_longlong, I, P]),
+    "uf_gelu_fwd": (I, [P, P, C.c_longlong, I, P]),
     "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),
     "uf_layernorm_bwd": (I, [P, I, P, P, I, P, I, P, P, I, I, P, c_size_t, P]),
     "uf_linear_wgrad_workspace_bytes": (c_size_t, [I, I, I]),

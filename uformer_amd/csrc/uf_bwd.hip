@@ -52,6 +52,20 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ a, 
     Vec<T>::store(dx + i * N, fd);
 }
 
+// y = GELU(a) as a separate pass (training forward: the pre-activation a is kept for GELU', so the activation cannot stay
+// fused in the GEMM epilogue without writing both).  Same flavour as the fused epilogues: erf form for f32 operands, the
+// packed sigmoid form for results stored as bf16 (uf_common.h gelu_n).
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ a, T* __restrict__ y, long long nvec) {
+    constexpr int N = Vec<T>::N;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvec) return;
+    float f[N];
+    Vec<T>::load(a + i * N, f);
+    gelu_n<T, N>(f);
+    Vec<T>::store(y + i * N, f);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm backward.  xhat = (x-mu)*rstd, g = dy*gamma:
 //   dx = rstd * (g - mean(g) - xhat * mean(g*xhat));  dgamma = sum_rows dy*xhat;  dbeta = sum_rows dy.
@@ -495,6 +509,20 @@ extern "C" int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n,
     if (dtype == UF_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)dy, (bf16*)dx, nvec);
     else hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)dy, (float*)dx, nvec);
     return check_launch("gelu_bwd");
+}
+
+extern "C" int uf_gelu_fwd(const void* a, void* y, long long n, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(a && y, UF_ERR_NULL, "uf_gelu_fwd: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_gelu_fwd: dtype %d", (int)dtype);
+    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(n > 0 && n % N == 0, UF_ERR_SHAPE, "uf_gelu_fwd: n=%lld must be a positive multiple of %d", n, N);
+    UF_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)y % 16) == 0, UF_ERR_ALIGN, "uf_gelu_fwd: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const long long nvec = n / N;
+    const dim3 grid((unsigned)((nvec + 255) / 256));
+    if (dtype == UF_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (bf16*)y, nvec);
+    else hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (float*)y, nvec);
+    return check_launch("gelu_fwd");
 }
 
 extern "C" size_t uf_layernorm_bwd_workspace_bytes(int rows, int C) {

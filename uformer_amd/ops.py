@@ -239,6 +239,17 @@ def dwconv3x3(x: Tensor, w9: Tensor, bias: Optional[Tensor] = None, gelu: bool =
     return out
 
 
+def gelu(a: Tensor) -> Tensor:
+    """GELU(a) as a separate pass (nn.GELU, model.py:657-660); bf16 / f32."""
+    _dev(a)
+    dt = uf_dtype(a.dtype)
+    a = _c(a)
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_gelu_fwd(_ptr(a), _ptr(out), a.numel(), dt, _stream()), "uf_gelu_fwd")
+    return out
+
+
 def gelu_bwd(a: Tensor, dy: Tensor) -> Tensor:
     """dy * GELU'(a), erf form (backward of nn.GELU, model.py:657-660).  a, dy: same shape and dtype (bf16 / f32)."""
     _dev(a, dy)

@@ -13,6 +13,7 @@ Eval-mode semantics (DropPath = identity), as the gradient fixtures.  model.py:9
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -24,6 +25,9 @@ Tensor = torch.Tensor
 
 
 Saved = Dict[str, object]
+# UF_TRAIN_SEPARATE_GELU=1: use uf_gelu_fwd instead of running linear1 and the depthwise conv twice in the training forward
+# (written at the end of round 1 without GPU time left to validate it, hence off by default; tests/test_gpu_next.py)
+_SEPARATE_GELU = os.environ.get("UF_TRAIN_SEPARATE_GELU", "0") == "1"
 Grads = Dict[str, Tensor]
 
 
@@ -65,9 +69,15 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     x1 = x2 + (br1 * s1 if s1 is not None else br1)
     z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
     a1 = ops.linear(z, w1, f("mlp.linear1.0.bias"))                          # pre-activation, kept for GELU'
-    h1 = ops.linear(z, w1, f("mlp.linear1.0.bias"), act=1).reshape(B, H, W, 4 * C)
-    c = ops.dwconv3x3(h1, w9, f("mlp.dwconv.0.bias"), gelu=False)            # pre-activation of the second GELU
-    g2 = ops.dwconv3x3(h1, w9, f("mlp.dwconv.0.bias"), gelu=True).reshape(M, 4 * C)
+    c_bias = f("mlp.dwconv.0.bias")
+    if _SEPARATE_GELU:                                                      # one GEMM / one stencil + an elementwise GELU pass each
+        h1 = ops.gelu(a1).reshape(B, H, W, 4 * C)
+        c = ops.dwconv3x3(h1, w9, c_bias, gelu=False)                       # pre-activation of the second GELU
+        g2 = ops.gelu(c).reshape(M, 4 * C)
+    else:                                                                   # activated copies recomputed by the fused-epilogue kernels
+        h1 = ops.linear(z, w1, f("mlp.linear1.0.bias"), act=1).reshape(B, H, W, 4 * C)
+        c = ops.dwconv3x3(h1, w9, c_bias, gelu=False)
+        g2 = ops.dwconv3x3(h1, w9, c_bias, gelu=True).reshape(M, 4 * C)
     br2 = ops.linear(g2, w2, f("mlp.linear2.0.bias")).float()
     y = x1 + (br2 * s2 if s2 is not None else br2)
     saved = dict(s1=s1, s2=s2, p=p, prefix=prefix, heads=heads, shift=shift, T=T, shape=(B, L, C), x2=x2, xn=xn, q=q, k=k, vt=vt, o=o, x1=x1, z=z, a1=a1,
