@@ -220,3 +220,30 @@ def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
     assert worst[0] < tol, worst
     for kname in [k for k in gd if k.startswith("g.")]:
         assert rel(params[kname[2:]].grad, t(gd[kname])) < tol, kname
+
+
+# ---- the separate GELU pass of the training forward (UF_TRAIN_SEPARATE_GELU, off by default until the training step is re-timed)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gelu_fwd(dtype):
+    from oracle import uformer_oracle as O
+    from uformer_amd import ops
+    a = (torch.randn(5, 33, 64) * 2).to(dtype)
+    ref = O.gelu_erf(a.float())
+    got = ops.gelu(a.cuda()).float().cpu()
+    assert (got - ref).abs().max() < (1e-6 if dtype == torch.float32 else 2.5e-2)
+
+
+def test_training_forward_with_separate_gelu_matches(monkeypatch):
+    """UF_TRAIN_SEPARATE_GELU path of uformer_amd/train.py against the default path (same block, same gradients)."""
+    import numpy as np
+    import os
+    from uformer_amd import train
+    gd = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "grad_lewin_block.npz")))
+    t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
+    p = {k[2:]: t(v).cuda() for k, v in gd.items() if k.startswith("p.")}
+    monkeypatch.setattr(train, "_SEPARATE_GELU", True)
+    y, dx, grads = train.lewin_block_forward_backward(t(gd["x"]).cuda(), p, "", int(gd["heads"]), 4, t(gd["gy"]).cuda(), torch.float32)
+    rel = lambda a, b: (a.float().cpu() - b).abs().max().item() / b.abs().max().item()    # noqa: E731
+    assert rel(y, t(gd["y"])) < 1e-3 and rel(dx, t(gd["dx"])) < 1e-3
+    for k, r in ((k[2:], t(v)) for k, v in gd.items() if k.startswith("g.")):
+        assert rel(grads[k], r) < 1e-3, k

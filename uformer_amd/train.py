@@ -26,7 +26,7 @@ Tensor = torch.Tensor
 
 Saved = Dict[str, object]
 # UF_TRAIN_SEPARATE_GELU=1: use uf_gelu_fwd instead of running linear1 and the depthwise conv twice in the training forward
-# (written at the end of round 1 without GPU time left to validate it, hence off by default; tests/test_gpu_next.py)
+# (validated on the GPU by tests/test_gpu_bwd.py; off by default until the training step has been re-timed with it)
 _SEPARATE_GELU = os.environ.get("UF_TRAIN_SEPARATE_GELU", "0") == "1"
 Grads = Dict[str, Tensor]
 
