@@ -247,3 +247,32 @@ def test_training_forward_with_separate_gelu_matches(monkeypatch):
     assert rel(y, t(gd["y"])) < 1e-3 and rel(dx, t(gd["dx"])) < 1e-3
     for k, r in ((k[2:], t(v)) for k, v in gd.items() if k.startswith("g.")):
         assert rel(grads[k], r) < 1e-3, k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
+    """BASELINE configs[2]/[3] geometry: Uformer-B 256x256 under the reference's Charbonnier loss.  Forward + backward through
+    the C-ABI kernels against the REFERENCE's autograd (tests/golden/grad_model_B_256.npz): loss, restored image, d loss /
+    d input, and EVERY one of the 719 parameter gradients through two signed random projections and a seeded gather or the
+    full tensor (tests/fixture_checks.py) -- a permuted or transposed gradient cannot pass.
+    Tolerances: f32 2e-3 (of ||g|| / max|g|), bf16 1e-1, the ones of the tiny32 test above."""
+    import fixture_checks as FC
+    from uformer_amd import spec, train
+    gd = golden("grad_model_B_256")
+    cfg = spec.arch_config("Uformer_B", img_size=256)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(1, 256, 256, 1234)
+    target = spec.synth_input(1, 256, 256, 1235)
+    # dL/dy at the REFERENCE forward output (the oracle's, pinned to it by tests/test_oracle_golden.py): see the tiny32 test
+    y_ref = O.uformer_forward(x, {k: v.cpu() for k, v in sd.items()}, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths,
+                              num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    loss_ref = O.charbonnier_loss(y_ref, target).item()
+    dy = OB.charbonnier_loss_bwd(y_ref, target)
+    y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype)
+    f32 = dtype == torch.float32
+    worst = FC.check_grad_B(gd, loss_ref, y, dimg, grads, rtol=2e-3 if f32 else 1e-1, loss_tol=1e-6, y_tol=1e-3 if f32 else 8e-3)
+    import json
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/parity_grad_B_{'f32' if f32 else 'bf16'}.json", "w") as f:
+        json.dump(worst, f)

@@ -254,3 +254,51 @@ def test_train_mode_droppath_forward_and_backward(golden):
         assert abs(val - s_abs) <= 5e-4 * s_abs + 1e-9, n
     for k, r in params(g, "g.").items():
         assert _rel(sd[k].grad, r) < GRAD_RTOL, k
+
+
+# ---- round-2 fixtures at the BASELINE.json sizes (tests/golden/make_golden_r2.py) -----------------------------------------
+def test_model_B_256_backward_charbonnier_every_parameter(golden):
+    """Uformer-B 256x256 (BASELINE configs[2]/[3] geometry): autograd through the oracle vs the reference's autograd, every one of
+    the 719 parameters through two signed random projections + a seeded gather (tests/fixture_checks.py)."""
+    import fixture_checks as FC
+    g = golden("grad_model_B_256")
+    cfg = spec.arch_config("Uformer_B", img_size=256)
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(1, 256, 256, 1234).requires_grad_(True)
+    target = spec.synth_input(1, 256, 256, 1235)
+    y = O.uformer_forward(x, sd, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    loss = O.charbonnier_loss(y, target)
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.is_floating_point()}
+    worst = FC.check_grad_B(g, loss.item(), y.detach(), x.grad, grads, rtol=GRAD_RTOL, loss_tol=1e-6, y_tol=5e-5)
+    assert worst["proj"] < GRAD_RTOL
+
+
+def test_model_B_720p_oracle_opt_in(golden):
+    """BASELINE configs[4] through the ORACLE (about two CPU-minutes on 8 cores): opt in with UF_SLOW_TESTS=1.  The GPU test
+    (tests/test_gpu_model.py::test_hires_720p_padded_to_1280) compares the HIP path with this same reference fixture directly."""
+    import os
+
+    import pytest
+    if os.environ.get("UF_SLOW_TESTS") != "1":
+        pytest.skip("opt-in (UF_SLOW_TESTS=1): 1280x1280 oracle forward takes minutes of CPU")
+    import fixture_checks as FC
+    g = golden("model_B_720p")
+    img = spec.synth_input(1, 720, 1280, 9)
+    xp, msk = O.expand2square(img, 128.0)
+    assert hashlib.sha256(xp.numpy().tobytes()).hexdigest() == str(g["x_sha256"])     # the reference's expand2square, bit for bit
+    cfg = spec.arch_config("Uformer_B", img_size=256)
+    sd = spec.synth_state_dict(cfg, 1234)
+    with torch.no_grad():
+        y = O.uformer_forward(xp, sd, img_size=256, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    frame = torch.masked_select(y, msk.bool()).reshape(1, 3, 720, 1280)
+    FC.check_720p(g, frame, 256, 1e-4, 2e-5)
+
+
+def test_expand2square_matches_reference_digest(golden):
+    """oracle.expand2square == the reference's own function (test/test_sidd.py:79-92) on the 720p frame: SHA-256 of the padded
+    square stored by make_golden_r2.py, which compiled the reference's function from its source text."""
+    g = golden("model_B_720p")
+    xp, msk = O.expand2square(spec.synth_input(1, 720, 1280, 9), 128.0)
+    assert hashlib.sha256(xp.numpy().tobytes()).hexdigest() == str(g["x_sha256"])
+    assert float(msk.sum()) == float(g["mask_sum"]) == 720 * 1280

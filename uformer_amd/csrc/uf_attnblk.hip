@@ -21,6 +21,7 @@
 // HBM traffic of the attention half: x once in, x once out, weights from L2 (+ h1 out when phase 3 runs).
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "uf_internal.h"
@@ -525,9 +526,11 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
 
 }  // namespace
 
-static unsigned long long* g_tbuf = nullptr;
-void debug_set_tbuf(void* p) { g_tbuf = (unsigned long long*)p; }
-unsigned long long* debug_get_tbuf() { return g_tbuf; }
+// development aid (uf_debug_set_tbuf): one pointer, read by every launch -- atomic so that a thread switching it on or off
+// never tears a concurrent launch's read
+static std::atomic<unsigned long long*> g_tbuf{nullptr};
+void debug_set_tbuf(void* p) { g_tbuf.store((unsigned long long*)p, std::memory_order_release); }
+unsigned long long* debug_get_tbuf() { return g_tbuf.load(std::memory_order_acquire); }
 
 // true when the fused kernel covers (dtype, C, head_dim); otherwise the caller uses the 3-kernel path
 bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads) {
@@ -548,7 +551,7 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     p.h1 = dtype == UF_BF16 ? h1_out : nullptr;   // phase 3 exists for 2-byte operands only
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
-    p.tbuf = g_tbuf;
+    p.tbuf = debug_get_tbuf();
 
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
     if (dtype == UF_BF16) {

@@ -447,13 +447,36 @@ class Uformer(nn.Module):
         self._packed = None
 
     def _get_packed(self, device):
-        params = list(self.parameters())
-        key = (self.compute_dtype, str(device), sum(p._version for p in params))
+        self._check_not_replica()
+        # (storage, version) of every parameter: catches in-place updates (optimizer steps bump _version) AND writes through
+        # ``p.data`` / ``p.data = ...`` that swap the storage without bumping it (EMA swaps, older optimizers)
+        key = (self.compute_dtype, str(device), tuple((p.data_ptr(), p._version) for p in self.parameters()))
         if self._packed is None or self._packed_key != key:
             sd = self.state_dict(keep_vars=True)
             self._packed = packing.PackedModel(self.cfg, sd, self.compute_dtype)
             self._packed_key = key
         return self._packed
+
+    def _check_not_replica(self):
+        """nn.DataParallel replicas carry no parameters of their own (``_parameters`` is emptied by ``replicate``) and would
+        share the packed weights / workspace of device 0.  The reference wraps the model in nn.DataParallel
+        (train/train_denoise.py:83); here multi-GPU is one process per GPU (uformer_amd.dist) -- say so instead of failing
+        with a KeyError deep inside the packing code."""
+        if getattr(self, "_is_replica", False):
+            raise UformerHipError("uformer_amd.Uformer cannot run as an nn.DataParallel replica: launch one process per GPU "
+                                  "(torch.distributed.run, uformer_amd.dist.shard_batch / GradientAllReduce) instead; "
+                                  "nn.DataParallel over a single device is fine")
+
+    def _workspace(self, need: int, device) -> Tensor:
+        """One workspace per (device, caller stream): two host threads driving the same module on their own streams must
+        not scribble over each other's activations."""
+        if self._ws is None:
+            self._ws = {}
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        return ws
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -462,9 +485,13 @@ class Uformer(nn.Module):
                                   "(the CPU oracle lives in oracle/ and is test infrastructure)")
         if x.dim() != 4 or x.shape[1] != self.dd_in:
             raise UformerHipError(f"expected (B,{self.dd_in},H,W) input, got {tuple(x.shape)}")
-        if self.training and torch.is_grad_enabled():
+        # autograd is wanted whenever grad mode is on and something upstream requires it -- in train() AND in eval() mode
+        # (fine-tuning with frozen statistics, input gradients): the fused inference kernels keep no activations and would
+        # return a tensor without grad_fn, i.e. silently drop the data term's gradients
+        if torch.is_grad_enabled() and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
             if mask is not None:
-                raise NotImplementedError("the mask argument is not supported by the training path (no reference script passes it)")
+                raise NotImplementedError("the mask argument is not supported by the autograd path (no reference script passes it): "
+                                          "wrap the call in torch.no_grad() for inference")
             return self._forward_train(x)
         if mask is not None:
             return self._forward_blockwise(x, mask)
@@ -477,11 +504,10 @@ class Uformer(nn.Module):
             need = lib.uf_uformer_workspace_bytes(pk.desc, B, H, W, dt)
             if need == 0:
                 raise UformerHipError("uf_uformer_workspace_bytes: " + _lib.last_error())
-            if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
-                self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            ws = self._workspace(need, x.device)
             out = torch.empty((B, self.in_chans, H, W), dtype=torch.float32, device=x.device)
-            _lib.check(lib.uf_uformer_fwd(pk.desc, xin.data_ptr(), out.data_ptr(), B, H, W, dt, self._ws.data_ptr(),
-                                          self._ws.numel(), torch.cuda.current_stream().cuda_stream), "uf_uformer_fwd")
+            _lib.check(lib.uf_uformer_fwd(pk.desc, xin.data_ptr(), out.data_ptr(), B, H, W, dt, ws.data_ptr(),
+                                          ws.numel(), torch.cuda.current_stream().cuda_stream), "uf_uformer_fwd")
         return out.to(x.dtype)
 
     def drop_path_rates(self):
@@ -494,10 +520,14 @@ class Uformer(nn.Module):
         kernels keep no activations).  DropPath masks are drawn here, per block and branch, as timm's DropPath does
         (train/train_denoise.py:181-184 then calls backward on the loss)."""
         from . import train
+        self._check_not_replica()
+        if self.embed_dim % 32 != 0:
+            raise NotImplementedError(f"the backward kernels are built for head_dim 32 (embed_dim a multiple of 32); embed_dim={self.embed_dim} "
+                                      "(Uformer_T, head_dim 16) runs inference only -- use torch.no_grad()")
         sd = self.state_dict(keep_vars=True)
         names, params = list(sd.keys()), list(sd.values())
-        rates = self.drop_path_rates()
-        drop = getattr(self, "_drop_scales_override", None)
+        rates = self.drop_path_rates() if self.training else []      # eval(): DropPath is the identity (timm)
+        drop = getattr(self, "_drop_scales_override", None) if self.training else None
         if drop is None and any(r > 0 for r in rates):
             drop = train.sample_drop_scales(rates, x.shape[0], x.device)
         return train.UformerFunction.apply(x, self.cfg, self.compute_dtype, drop, names, *params)

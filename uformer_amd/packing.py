@@ -76,8 +76,10 @@ def pack_output_proj(w: Tensor) -> Tensor:
 
 def pack_block(sd: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype: torch.dtype):
     """Returns (BlockParams, keepalive list).  ``sd`` maps reference keys to tensors on the GPU."""
-    f = lambda k: sd[prefix + k].detach().contiguous().float()  # noqa: E731
-    t = lambda k: sd[prefix + k].detach().contiguous().to(dtype)  # noqa: E731
+    # small f32 tensors are COPIED, never aliased: the packed block must stay valid when a parameter's storage is replaced
+    # (p.data = ..., EMA swaps) until the owner notices the new (data_ptr, _version) key and repacks
+    f = lambda k: sd[prefix + k].detach().float().clone().contiguous()  # noqa: E731
+    t = lambda k: sd[prefix + k].detach().to(dtype, copy=True).contiguous()  # noqa: E731
     wqkv = torch.cat([sd[prefix + "attn.qkv.to_q.weight"].detach(), sd[prefix + "attn.qkv.to_kv.weight"].detach()], 0)
     dense = rpb_dense(sd[prefix + "attn.relative_position_bias_table"], sd[prefix + "attn.relative_position_index"])
     keep: Dict[str, Tensor] = {
@@ -130,18 +132,18 @@ class PackedModel:
         d.blocks = C.cast(self.blocks, C.POINTER(_lib.BlockParams))
         g = {
             "in_w27": pack_input_proj(sd["input_proj.proj.0.weight"]),
-            "in_b": sd["input_proj.proj.0.bias"].detach().contiguous().float(),
+            "in_b": sd["input_proj.proj.0.bias"].detach().float().clone().contiguous(),
             "out_w": pack_output_proj(sd["output_proj.proj.0.weight"]),
-            "out_b": sd["output_proj.proj.0.bias"].detach().contiguous().float(),
+            "out_b": sd["output_proj.proj.0.bias"].detach().float().clone().contiguous(),
         }
         for name, tns in g.items():
             setattr(d, name, tns.data_ptr())
         self.keep.append(g)
         for k in range(4):
             dw = pack_downsample(sd[f"dowsample_{k}.conv.0.weight"], dtype)
-            db = sd[f"dowsample_{k}.conv.0.bias"].detach().contiguous().float()
+            db = sd[f"dowsample_{k}.conv.0.bias"].detach().float().clone().contiguous()
             uw = pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], dtype)
-            ub = sd[f"upsample_{k}.deconv.0.bias"].detach().contiguous().float()
+            ub = sd[f"upsample_{k}.deconv.0.bias"].detach().float().clone().contiguous()
             d.down_w[k], d.down_b[k], d.up_w[k], d.up_b[k] = dw.data_ptr(), db.data_ptr(), uw.data_ptr(), ub.data_ptr()
             self.keep.append((dw, db, uw, ub))
         self.desc = d
