@@ -234,6 +234,53 @@ size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);
 int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C,
                        uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- f-2: training-step tail ------------------------------------------------------------------------------
+ * CharbonnierLoss.forward + its gradient in one pass (losses.py:41-52; criterion of train/train_denoise.py:164,181):
+ *   loss[0] = mean(sqrt((y - target)^2 + eps^2));   dy[i] = grad_scale * (y - target)[i] / sqrt(.) / n   (dy may be NULL)
+ * y, target, dy: f32[n] (any shape flattened), 16-byte aligned.  Two-stage fixed-order reduction in double through `ws`
+ * (uf_charbonnier_workspace_bytes): bit-reproducible.  The restored image y already contains the global residual
+ * (uf_output_proj_fwd adds it, model.py:1305). */
+size_t uf_charbonnier_workspace_bytes(long long n);
+int uf_charbonnier_fwd_bwd(const float* y, const float* target, float* dy, float* loss, long long n, float eps,
+                           float grad_scale, void* ws, size_t ws_bytes, void* stream);
+/* torch.optim.AdamW(lr, betas, eps, weight_decay) (train/train_denoise.py:77: 2e-4, (0.9,0.999), 1e-8, 0.02), one step for
+ * n_tensors parameters in a handful of launches (40 tensors per launch, arguments by value: nothing is allocated or retained).
+ * params / grads / exp_avg / exp_avg_sq / numel are HOST arrays of device pointers / element counts; state is f32.  `step`
+ * counts from 1 (bias correction); gradients are multiplied by grad_scale first (1 / world_size folds the all-reduce average).
+ *   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * (hyper-parameters are doubles and the derived scalars are rounded to f32 once, exactly as torch rounds its Python scalars) */
+int uf_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                  const long long* numel, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+                  int step, double grad_scale, void* stream);
+
+/* ---- f-3: evaluation metrics on the device ------------------------------------------------------------------------
+ * per-image mean squared difference of (optionally [0,1]-clamped) images: myPSNR = 20 log10(1 / sqrt(mse)) and batch_PSNR
+ * (utils/image_utils.py:40-51) follow from it without copying an image to the host.  a, b: f32 (n_images, C, H, W). */
+size_t uf_image_metric_workspace_bytes(int n_images, int C, int H, int W);
+int uf_batch_mse(const float* a, const float* b, float* mse_per_image, int n_images, int C, int H, int W, int clamp01,
+                 void* ws, size_t ws_bytes, void* stream);
+/* calculate_ssim (utils/caculate_psnr_ssim.py:35-81): images quantised to uint8 levels (x255, round, clamp), 11x11 Gaussian
+ * sigma 1.5, "valid" region, mean over the map and over channels; one value per image.  H, W > 10. */
+int uf_batch_ssim(const float* a, const float* b, float* ssim_per_image, int n_images, int C, int H, int W, void* ws,
+                  size_t ws_bytes, void* stream);
+
+/* ---- f-1: arbitrary-resolution wrapper of the evaluation scripts ----------------------------------------------------
+ * expand2square (test/test_sidd.py:79-92): canvas f32 (B,C,X,X) = 0 with the (B,C,h,w) image at ((X-h)/2, (X-w)/2); mask
+ * (B,1,X,X) = 1 over the image (may be NULL).  One pass, no memset.  uf_crop_clamp is the way back (masked_select + clamp,
+ * test/test_sidd.py:108-109). */
+int uf_expand2square(const float* img, float* canvas, float* mask, int B, int C, int h, int w, int X, void* stream);
+int uf_crop_clamp(const float* canvas, float* out, int B, int C, int h, int w, int X, int clamp01, void* stream);
+
+/* ---- f-4: training input pipeline on the device ---------------------------------------------------------------------
+ * DataLoaderTrain.__getitem__ (dataset/dataset_denoise.py:42-73) for a whole batch: out[b] = T_k(frame[idx][:, r0:r0+ps,
+ * c0:c0+ps]) with T_k = Augment_RGB_torch.transform<k> (utils/dataset_utils.py:5-33), k in 0..7.  src: N frames, uint8
+ * (divided by 255 like load_img) or f32, layout (N,H,W,3) (src_hwc = 1) or (N,3,H,W); meta: int32 [B][4] = {idx, r0, c0, k}
+ * on the device; out f32 (B,3,ps,ps).  Call it twice with the same meta for the clean / noisy pair. */
+int uf_crop_augment(const void* src, int src_is_u8, int src_hwc, float* out, const int* meta, int B, int N, int H, int W,
+                    int ps, void* stream);
+/* MixUp_AUG.aug (utils/dataset_utils.py:37-53): out[b] = lam[b] x[b] + (1 - lam[b]) x[perm[b]]; out must not alias x. */
+int uf_mixup(const float* x, float* out, const float* lam, const int* perm, int B, long long per_sample, void* stream);
+
 /* ---- a9 (boundary): Uformer.forward (model.py:1269-1305) ------------------------------------ */
 typedef struct uf_model_desc {
     int32_t embed_dim, dd_in, in_chans;

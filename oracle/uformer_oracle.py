@@ -323,3 +323,49 @@ def psnr(a: Tensor, b: Tensor) -> float:
     d = torch.clamp(a, 0, 1) - torch.clamp(b, 0, 1)
     rmse = float((d ** 2).mean().sqrt())
     return float("inf") if rmse == 0 else 20.0 * math.log10(1.0 / rmse)
+
+
+# ---- the steps either side of the path: metrics, augmentation -- restated for the tests ------------------------------
+def batch_psnr(img1: Tensor, img2: Tensor, average: bool = True) -> float:
+    """batch_PSNR: per-image myPSNR summed / averaged.  utils/image_utils.py:46-51."""
+    ps = [psnr(a, b) for a, b in zip(img1, img2)]
+    return sum(ps) / len(ps) if average else sum(ps)
+
+
+def ssim(img1: Tensor, img2: Tensor) -> float:
+    """calculate_ssim on float (C,H,W) images in [0,1]: x255, round, uint8; per channel the 11x11 Gaussian (sigma 1.5) statistics
+    on the valid region (cv2.filter2D(...)[5:-5, 5:-5] == valid correlation), mean over the map, mean over channels.
+    utils/caculate_psnr_ssim.py:35-81 (crop_border 0, test_y_channel False)."""
+    import numpy as np
+    from scipy.signal import correlate2d
+    a = np.uint8((img1.clamp(0, 1).numpy() * 255.0).round()).astype(np.float64)
+    b = np.uint8((img2.clamp(0, 1).numpy() * 255.0).round()).astype(np.float64)
+    k = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
+    k /= k.sum()                                     # cv2.getGaussianKernel(11, 1.5)
+    window = np.outer(k, k)
+    C1, C2 = (0.01 * 255) ** 2, (0.03 * 255) ** 2
+    vals = []
+    for c in range(a.shape[0]):
+        f = lambda z: correlate2d(z, window, mode="valid")   # noqa: E731
+        mu1, mu2 = f(a[c]), f(b[c])
+        s1, s2, s12 = f(a[c] ** 2) - mu1 ** 2, f(b[c] ** 2) - mu2 ** 2, f(a[c] * b[c]) - mu1 * mu2
+        m = ((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 ** 2 + mu2 ** 2 + C1) * (s1 + s2 + C2))
+        vals.append(m.mean())
+    return float(np.mean(vals))
+
+
+def augment(x: Tensor, k: int) -> Tensor:
+    """Augment_RGB_torch.transform<k> (utils/dataset_utils.py:8-33): rot90 by k & 3 in dims [-1,-2], then flip(-2) for k >= 4."""
+    y = torch.rot90(x, k=k & 3, dims=[-1, -2])
+    return y.flip(-2) if k >= 4 else y
+
+
+def crop_augment(frame_chw: Tensor, r: int, c: int, ps: int, k: int) -> Tensor:
+    """DataLoaderTrain.__getitem__ after loading: crop [r:r+ps, c:c+ps] then the transform.  dataset/dataset_denoise.py:54-70."""
+    return augment(frame_chw[:, r:r + ps, c:c + ps], k)
+
+
+def mixup(x: Tensor, lam: Tensor, perm: Tensor) -> Tensor:
+    """MixUp_AUG.aug for one tensor: lam x + (1 - lam) x[perm].  utils/dataset_utils.py:44-53."""
+    lam = lam.view(-1, 1, 1, 1)
+    return lam * x + (1 - lam) * x[perm]

@@ -1,0 +1,179 @@
+"""SURVEY section 8f rows through the C ABI on the GPU: training-step tail (Charbonnier, AdamW), metrics (PSNR, SSIM), the
+arbitrary-resolution wrapper (expand2square / crop + clamp / tiled restore) and the device input pipeline (crop + rot/flip, MixUp),
+each against the reference's formula restated in the oracle or against torch's own CPU implementation."""
+import io
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import uformer_oracle as O
+from uformer_amd import spec
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 64, 64), (1, 3, 37, 53), (32, 3, 256, 256)])
+def test_charbonnier_loss_and_gradient(shape):
+    """loss and d loss / d restored of losses.py:41-52 in one pass vs autograd through the oracle's formula; bit-reproducible."""
+    from uformer_amd import losses, ops
+    y = torch.rand(shape, generator=g(1)) * 1.2 - 0.1
+    t = torch.rand(shape, generator=g(2))
+    yr = y.clone().requires_grad_(True)
+    ref = O.charbonnier_loss(yr, t)
+    ref.backward()
+    loss, dy = ops.charbonnier(y.cuda(), t.cuda())
+    loss2, dy2 = ops.charbonnier(y.cuda(), t.cuda())
+    assert torch.equal(loss, loss2) and torch.equal(dy, dy2)
+    assert abs(loss.item() - ref.item()) <= 2e-7 * max(1.0, abs(ref.item()))
+    assert (dy.cpu() - yr.grad).abs().max().item() <= 1e-6 * yr.grad.abs().max().item()
+    # the nn.Module form with autograd on both arguments (train/train_denoise.py:181)
+    a, b = y.cuda().requires_grad_(True), t.cuda().requires_grad_(True)
+    l3 = losses.CharbonnierLoss()(a, b)
+    (l3 * 3.0).backward()
+    assert torch.allclose(a.grad.cpu(), 3.0 * yr.grad, rtol=1e-5, atol=1e-12) and torch.allclose(b.grad.cpu(), -3.0 * yr.grad, rtol=1e-5, atol=1e-12)
+
+
+def test_adamw_three_steps_vs_torch_cpu():
+    """uf_adamw_step vs torch.optim.AdamW on the CPU with the reference's hyper-parameters (train/train_denoise.py:77), 3 steps,
+    110 tensors of assorted sizes (scalars, unaligned lengths, > one 8192-element chunk, > 40 tensors = several launches)."""
+    from uformer_amd import optim
+    sizes = [(1,), (3,), (7, 5), (64,), (225, 2), (128, 32), (8193,), (4, 1, 3, 3), (1024, 256)] + [(17 + i, 3) for i in range(101)]
+    ps_cpu = [torch.randn(s, generator=g(10 + i)).requires_grad_(True) for i, s in enumerate(sizes)]
+    ps_gpu = [p.detach().clone().cuda().requires_grad_(True) for p in ps_cpu]
+    kw = dict(lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    oc, og = torch.optim.AdamW(ps_cpu, **kw), optim.AdamW(ps_gpu, **kw)
+    for step in range(3):
+        for i, (pc, pg) in enumerate(zip(ps_cpu, ps_gpu)):
+            gr = torch.randn(pc.shape, generator=g(1000 * step + i)) * (10.0 ** ((i % 5) - 3))
+            pc.grad, pg.grad = gr.clone(), gr.clone().cuda()
+        oc.step(); og.step()
+    for pc, pg in zip(ps_cpu, ps_gpu):
+        assert torch.allclose(pg.detach().cpu(), pc.detach(), rtol=1e-6, atol=1e-9), (pc.shape, (pg.detach().cpu() - pc.detach()).abs().max())
+    for pc, pg in zip(ps_cpu, ps_gpu):
+        sc, sg = oc.state[pc], og.state[pg]
+        assert int(sc["step"]) == int(sg["step"]) == 3
+        assert torch.allclose(sg["exp_avg"].cpu(), sc["exp_avg"], rtol=1e-6, atol=1e-12)
+        assert torch.allclose(sg["exp_avg_sq"].cpu(), sc["exp_avg_sq"], rtol=1e-6, atol=1e-14)
+    # grad_scale = 1/world folds the all-reduce average: same as stepping on g/4
+    p1, p2 = torch.randn(5000, generator=g(5)).cuda().requires_grad_(True), None
+    p2 = p1.detach().clone().requires_grad_(True)
+    o1, o2 = optim.AdamW([p1], **kw), optim.AdamW([p2], **kw)
+    gr = torch.randn(5000, generator=g(6)).cuda()
+    p1.grad, p2.grad = gr.clone(), gr / 4
+    o1.step(grad_scale=0.25); o2.step()
+    assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-9)
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """{'epoch','state_dict','optimizer'} written by us loads into torch.optim.AdamW / a fresh model, and a dict written the
+    reference's way (torch.optim.AdamW state, 'module.' prefix) resumes our optimizer (train/train_denoise.py:101-119,207-235)."""
+    from uformer_amd import checkpoint, model, optim
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 3)
+    m = model.Uformer(img_size=128, embed_dim=32, depths=list(cfg.depths), modulator=True, compute_dtype=torch.float32)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    opt = optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    for p in m.parameters():
+        p.grad = torch.randn_like(p) * 1e-2
+    opt.step()
+    path = str(tmp_path / "model_latest.pth")
+    checkpoint.save_training_state(path, 7, m, opt, data_parallel_prefix=True)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "state_dict", "optimizer"} and all(k.startswith("module.") for k in ck["state_dict"])
+    assert checkpoint.load_start_epoch(path) == 7
+    m2 = model.Uformer(img_size=128, embed_dim=32, depths=list(cfg.depths), modulator=True, compute_dtype=torch.float32)
+    checkpoint.load_checkpoint(m2, path)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a.cpu(), b.cpu()), k
+    ref_opt = torch.optim.AdamW(m2.parameters(), lr=1.0)            # the reference's optimizer class resumes from our file
+    assert checkpoint.load_optim(ref_opt, path) == 2e-4
+    m2 = m2.cuda()
+    opt2 = optim.AdamW(m2.parameters(), lr=1.0)
+    buf = io.BytesIO()
+    torch.save({"epoch": 8, "state_dict": m2.state_dict(), "optimizer": ref_opt.state_dict()}, buf)    # a reference-written file
+    p2 = str(tmp_path / "ref.pth")
+    open(p2, "wb").write(buf.getvalue())
+    assert checkpoint.load_optim(opt2, p2) == 2e-4
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    for p in m2.parameters():
+        p.grad = torch.full_like(p, 1e-3)
+    opt.step(); opt2.step()
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
+
+
+def test_batch_psnr_and_ssim_vs_reference_formulas():
+    from uformer_amd import metrics
+    a = torch.rand(3, 3, 72, 200, generator=g(1)) * 1.3 - 0.15             # values outside [0,1]: the clamp matters
+    b = (a + 0.05 * torch.randn(a.shape, generator=g(2))).clamp(-0.2, 1.2)
+    ref = O.batch_psnr(a, b, average=False)
+    got = metrics.batch_PSNR(a.cuda(), b.cuda(), average=False).item()
+    assert abs(got - ref) <= 1e-4 * abs(ref)
+    assert abs(metrics.myPSNR(a[0].cuda(), b[0].cuda()).item() - O.psnr(a[0], b[0])) <= 1e-4
+    s = metrics.batch_SSIM(a.cuda(), b.cuda(), average=False).cpu()
+    for i in range(3):
+        assert abs(s[i].item() - O.ssim(a[i], b[i])) <= 1e-5, (i, s[i].item(), O.ssim(a[i], b[i]))
+
+
+def test_expand2square_and_crop_clamp_kernels():
+    from uformer_amd import ops
+    for (h, w) in ((720, 1280), (200, 136), (128, 128), (130, 3)):
+        img = spec.synth_input(2, h, w, 5) * 1.4 - 0.2
+        ref_c, ref_m = O.expand2square(img[:1], 128.0)
+        c, m = ops.expand2square(img.cuda(), 128.0)
+        assert torch.equal(c[:1].cpu(), ref_c) and torch.equal(m[:1].cpu(), ref_m)
+        ref_c1, _ = O.expand2square(img[1:], 128.0)
+        assert torch.equal(c[1:].cpu(), ref_c1)
+        back = ops.crop_clamp(c, h, w, clamp=True).cpu()
+        exp = torch.clamp(torch.masked_select(ref_c, ref_m.bool()).reshape(1, 3, h, w), 0, 1)
+        assert torch.equal(back[:1], exp)
+        assert torch.equal(ops.crop_clamp(c, h, w, clamp=False).cpu(), img)
+
+
+def test_crop_augment_and_mixup_vs_reference_transforms():
+    from uformer_amd import data, ops
+    N, H, W, ps = 5, 96, 80, 48
+    frames_u8 = torch.randint(0, 256, (N, H, W, 3), generator=g(3), dtype=torch.uint8)       # as cv2 decodes: HWC uint8
+    frames_f = (frames_u8.float() / 255.0).permute(0, 3, 1, 2).contiguous()                 # load_img + permute(2,0,1)
+    meta = torch.tensor([[i % N, (7 * i) % (H - ps), (11 * i) % (W - ps), i % 8] for i in range(16)], dtype=torch.int32)
+    ref = torch.stack([O.crop_augment(frames_f[i], r, c, ps, k) for i, r, c, k in meta.tolist()])
+    got_u8 = ops.crop_augment(frames_u8.cuda(), meta.cuda(), ps, hwc=True).cpu()
+    got_f = ops.crop_augment(frames_f.cuda(), meta.cuda(), ps, hwc=False).cpu()
+    assert torch.equal(got_u8, ref) and torch.equal(got_f, ref)
+    loader = data.GpuPatchLoader(frames_u8.cuda(), frames_u8.flip(0).cuda(), ps)
+    cl, no = loader.batch(8)
+    assert cl.shape == no.shape == (8, 3, ps, ps) and cl.min() >= 0 and cl.max() <= 1
+    lam = torch.rand(16, generator=g(4))
+    perm = torch.randperm(16, generator=g(5))
+    assert torch.allclose(ops.mixup(ref.cuda(), lam.cuda(), perm.cuda().int()).cpu(), O.mixup(ref, lam, perm), rtol=0, atol=1e-7)
+    a, b = data.MixUp_AUG().aug(cl, no)
+    assert a.shape == cl.shape and torch.isfinite(a).all() and torch.isfinite(b).all()
+
+
+def test_restore_tiled_matches_single_tile_and_tracks_full_frame():
+    """restore_tiled == restore when the image fits one tile; on a 384x640 frame cut into overlapping 384-tiles it stays close
+    to the full-frame (padded to 640x640) result -- it is an approximation by construction, the number is reported."""
+    from uformer_amd import infer, model
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 5)
+    m = model.Uformer(img_size=128, embed_dim=32, depths=list(cfg.depths), modulator=True, compute_dtype=torch.float32).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    img = spec.synth_input(1, 200, 136, 11).cuda()
+    assert torch.equal(infer.restore_tiled(m, img, tile=256), infer.restore(m, img))
+    img = spec.synth_input(1, 384, 640, 12).cuda()
+    full = infer.restore(m, img)
+    tiled = infer.restore_tiled(m, img, tile=384, min_overlap=128)
+    assert tiled.shape == full.shape and torch.isfinite(tiled).all()
+    ps = O.psnr(tiled.cpu(), full.cpu())
+    import json, os
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump({"psnr_tiled_vs_full_db": ps}, open("gpurun_out/parity_tiled.json", "w"))
+    assert ps >= 30.0, ps

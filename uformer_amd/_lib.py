@@ -79,6 +79,16 @@ SIGNATURES = {
     "uf_upsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "uf_input_proj_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "uf_output_proj_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+    "uf_charbonnier_workspace_bytes": (c_size_t, [C.c_longlong]),
+    "uf_charbonnier_fwd_bwd": (I, [P, P, P, P, C.c_longlong, C.c_float, C.c_float, P, c_size_t, P]),
+    "uf_adamw_step": (I, [P, P, P, P, P, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, C.c_double, P]),
+    "uf_image_metric_workspace_bytes": (c_size_t, [I, I, I, I]),
+    "uf_batch_mse": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
+    "uf_batch_ssim": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),
+    "uf_expand2square": (I, [P, P, P, I, I, I, I, I, P]),
+    "uf_crop_clamp": (I, [P, P, I, I, I, I, I, I, P]),
+    "uf_crop_augment": (I, [P, I, I, P, P, I, I, I, I, I, P]),
+    "uf_mixup": (I, [P, P, P, P, I, C.c_longlong, P]),
     "uf_uformer_workspace_bytes": (c_size_t, [C.POINTER(ModelDesc), I, I, I, I]),
     "uf_uformer_fwd": (I, [C.POINTER(ModelDesc), P, P, I, I, I, I, P, c_size_t, P]),
 }

@@ -45,6 +45,20 @@ struct AttnBlkParams {
 
 constexpr float LOG2E = 1.4426950408889634f;
 
+// weight-fragment ring depths (k-steps of L2 -> register loads in flight) of the three GEMM phases at C >= 256
+#ifndef UF_LN_ROTATE
+#define UF_LN_ROTATE 1
+#endif
+#ifndef UF_QKV_RING
+#define UF_QKV_RING 3
+#endif
+#ifndef UF_PROJ_RING
+#define UF_PROJ_RING 3
+#endif
+#ifndef UF_FC1_RING
+#define UF_FC1_RING 5
+#endif
+
 template <typename T> struct FragFromAcc;
 template <> struct FragFromAcc<bf16> {
     static __device__ __forceinline__ void make(Frag<bf16>& f, f32x4 a, f32x4 b) {
@@ -69,9 +83,11 @@ template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // bala
 // through a 3-deep ring pinned with sched_barrier, first k-steps of the next unit issued before the epilogue, and the
 // permlane-widened direct 16-byte stores.  2-byte operand types only.
 template <typename T, int C, int WAVES>
-__device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, const float* b1, T* h1, int m0, int H, int W, int shift,
+__device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, const float* b1, T* h1, const WinGeom& geo,
                                           int wave, int lane) {
-    constexpr int SZ = sizeof(T), KS = C / 32, RING = 3, N4 = 4 * C, UNITS = N4 / 64;
+    // RING k-steps of weight fragments in flight: one k-step is only 16 MFMAs (256 cycles) per wave, an L2 round trip under
+    // load is 1-2 K cycles -- with 3 slots the walk stalled on every k-step (stamps: 3-4x the MFMA time); 16 registers a slot
+    constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / 64;
     static_assert(SZ == 2, "direct-store epilogue packs bf16 pairs");
     const int fr = lane & 15, fg = lane >> 4;
     const T* wrow[4];
@@ -89,7 +105,7 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
     };
     size_t rowoff[4];   // h1 row of this lane's token in each 16-row tile (window_reverse + roll back, as the residual rows)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) rowoff[j] = (size_t)window_row_to_token(m0 + j * 16 + fr, H, W, shift) * N4;
+    for (int j = 0; j < 4; ++j) rowoff[j] = (size_t)window_token(geo, j * 16 + fr) * N4;
     if (wave < UNITS) unit_prefetch(wave);
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
@@ -106,6 +122,9 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
             for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(arow + j * 16 * SA + ks * 32 * SZ));
         };
         aload(0, 0);
+        f32x4 bv[4];   // the unit's bias: requested here, consumed after the k-loop (was an exposed L2 round trip per unit)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(b1 + nbase + i * 16 + fg * 4);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + RING - 1 < KS) wload(ks + RING - 1, (ks + RING - 1) % RING);
@@ -119,9 +138,6 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
         }
         if (u + WAVES < UNITS) unit_prefetch(u + WAVES);
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(b1 + nbase + i * 16 + fg * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
@@ -154,12 +170,13 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     char* Os = smem + 64 * SA;
     float* Tab = reinterpret_cast<float*>(smem + 2 * 64 * SA);   // [HEADS][225] compact rel-pos bias
     float* Red = Tab + HEADS * 225;                               // [2][WAVES][64] LN2 partial sums (phase 3)
+    float* Bq = Red + 2 * WAVES * 64;                             // [3C] q/k/v bias + [C] proj bias: read from LDS inside the unit walks, not from L2
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
     const int bw = blockIdx.x;                      // window index (image-major, as window_partition)
-    const int m0 = bw * 64;
+    const WinGeom geo = window_geom(bw, p.H, p.W, p.shift);      // window coordinates once (scalar unit), rows by adds
     auto stamp = [&](int k) {
         if (p.tbuf && lane == 0 && (bw & 63) == 0) p.tbuf[((bw >> 6) * WAVES + wave) * 16 + k] = __builtin_readcyclecounter();
     };
@@ -175,18 +192,23 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         constexpr int U = (16 / V4) < NP ? (16 / V4) : NP;   // 16 x 16-byte loads in flight per thread
         static_assert(NP >= 1 && NP % U == 0, "pass batching");
         const int sub = tid % LPR;
+        // the order in which a workgroup walks its rows is rotated by the window index: all workgroups start together, and with
+        // one fixed order the addresses requested at any moment differ only in the window bits (several address bits are the
+        // same chip-wide -> the requests of a round pile up on a subset of the memory channels)
+        static_assert((U & (U - 1)) == 0, "U is a power of two");
+        const int rot = UF_LN_ROTATE ? bw : 0;
 #pragma unroll 1
         for (int r0 = 0; r0 < 64; r0 += RPP * U) {
             f32x4 v[U][V4];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int src = window_row_to_token(m0 + r0 + u * RPP + tid / LPR, p.H, p.W, p.shift);
+                const int src = window_token(geo, r0 + ((u + rot) & (U - 1)) * RPP + tid / LPR);
 #pragma unroll
                 for (int i = 0; i < V4; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int row = r0 + u * RPP + tid / LPR;
+                const int row = r0 + ((u + rot) & (U - 1)) * RPP + tid / LPR;
                 float sum = 0.f;
 #pragma unroll
                 for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
@@ -211,6 +233,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         }
     }
     for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i] * LOG2E;   // scores live in the log2 domain (see softmax)
+    for (int i = tid; i < 4 * C; i += NT) Bq[i] = i < 3 * C ? p.bqkv[i] : p.bp[i - 3 * C];
     stamp(1);
     lds_barrier();
     stamp(2);
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;   // fragment-major tiles
         // weight fragments come from L2 (>= 500 cycles): ring of WR k-steps in flight where registers allow; the
         // activation fragments come from LDS, one step ahead is enough
-        constexpr int WR = (SZ == 2 && C >= 128) ? 3 : 2;
+        constexpr int WR = (SZ == 2 && C >= 256) ? UF_QKV_RING : ((SZ == 2 && C >= 128) ? 3 : 2);
         Frag<T> wf[WR][6], af[2][4];
         Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
         auto wload = [&](int ks, int slot) {
@@ -284,9 +307,9 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         // bias (+ scale on q, model.py:497), then the accumulators ARE the attention operands
         Frag<T> qf[QT], kf[4], vtf[2][2];
         {
-            const f32x4 bq0 = *reinterpret_cast<const f32x4*>(p.bqkv + h * 32 + fg * 4), bq1 = *reinterpret_cast<const f32x4*>(p.bqkv + h * 32 + 16 + fg * 4);
-            const f32x4 bk0 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(p.bqkv + C + h * 32 + 16 + fg * 4);
-            const float bv0 = p.bqkv[2 * C + h * 32 + fr], bv1 = p.bqkv[2 * C + h * 32 + 16 + fr];
+            const f32x4 bq0 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + fg * 4), bq1 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + 16 + fg * 4);
+            const f32x4 bk0 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + 16 + fg * 4);
+            const float bv0 = Bq[2 * C + h * 32 + fr], bv1 = Bq[2 * C + h * 32 + 16 + fr];
 #pragma unroll
             for (int j = 0; j < QT; ++j) FragFromAcc<T>::make(qf[j], (aq[0][j] + bq0) * p.qscale, (aq[1][j] + bq1) * p.qscale);   // qscale carries log2(e)
 #pragma unroll
@@ -412,7 +435,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         for (int i = 0; i < TNW; ++i)
 #pragma unroll
             for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int PR = SZ == 2 ? 3 : 2;   // weight ring depth (k-steps in flight)
+        constexpr int PR = SZ == 2 ? (KS >= 8 ? UF_PROJ_RING : 3) : 2;   // weight ring depth (k-steps in flight)
         Frag<T> wf[PR][TNW], af[2][TMW];
         auto wload = [&](int ks, int slot) {
 #pragma unroll
@@ -426,6 +449,21 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         for (int pf = 0; pf < PR - 1; ++pf)
             if (pf < KS) wload(pf, pf);
         aload(0, 0);
+        // the rows this wave updates: addresses now, and (2-byte operand types: registers allow it) the residual values and
+        // the bias requested BEFORE the k-loop, so that their round trip (L2: the rows were read in phase 0) hides under it
+        float* xrow[TMW];
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) xrow[j] = p.x + (size_t)window_token(geo, (wm * TMW + j) * 16 + fr) * p.ld;
+        constexpr bool PRE = SZ == 2;
+        f32x4 res[PRE ? TNW : 1][PRE ? TMW : 1];
+        if constexpr (PRE) {
+#pragma unroll
+            for (int i = 0; i < TNW; ++i) {
+                const int n = (wn * TNW + i) * 16 + fg * 4;
+#pragma unroll
+                for (int j = 0; j < TMW; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(xrow[j] + n);
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + PR - 1 < KS) wload(ks + PR - 1, (ks + PR - 1) % PR);
@@ -440,13 +478,13 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
         stamp(7);
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
-            const int tok = window_row_to_token(m0 + (wm * TMW + j) * 16 + fr, p.H, p.W, p.shift);
-            float* xr = p.x + (size_t)tok * p.ld;
+            float* xr = xrow[j];
 #pragma unroll
             for (int i = 0; i < TNW; ++i) {
                 const int n = (wn * TNW + i) * 16 + fg * 4;
-                const f32x4 b = *reinterpret_cast<const f32x4*>(p.bp + n);
-                acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);   // the block's new rows stay in registers
+                const f32x4 b = *reinterpret_cast<const f32x4*>(Bq + 3 * C + n);
+                if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b);   // the block's new rows stay in registers
+                else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);
                 *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
             }
         }
@@ -499,7 +537,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     if constexpr (SZ == 2) {
         if (p.h1) {
             lds_barrier();
-            fc1_units<T, C, WAVES>(Xn, SA, reinterpret_cast<const T*>(p.W1), p.b1, reinterpret_cast<T*>(p.h1), m0, p.H, p.W, p.shift, wave, lane);
+            fc1_units<T, C, WAVES>(Xn, SA, reinterpret_cast<const T*>(p.W1), p.b1, reinterpret_cast<T*>(p.h1), geo, wave, lane);
         }
     }
     census.end(p.tbuf, bw);
@@ -507,7 +545,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
 
 template <typename T, int C, int NT>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
-    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4;
+    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT>;
     static bool lds_done[64] = {};

@@ -27,7 +27,7 @@ struct Leff2Params {
     unsigned long long* tbuf;   // optional per-role cycle totals of sampled blocks (uf_debug_set_tbuf)
 };
 
-constexpr int KC = 64;  // hidden channels per chunk
+constexpr int KCW = 64;  // hidden channels one producer group (4 waves) convolves per interval
 
 template <typename T> __device__ __forceinline__ void cvt8(const char* p, float* f);
 template <> __device__ __forceinline__ void cvt8<bf16>(const char* p, float* f) {
@@ -47,65 +47,143 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-// Wave-specialised version.  NP + NC waves; the hardware places waves w, w+4, w+8 of a workgroup on the same
-// SIMD, so every SIMD hosts one PRODUCER wave (0..NP-1: depthwise stencil + GELU, pure VALU/LDS) and NC/4 CONSUMER
-// waves (halo + tap + W2 traffic, MFMAs, epilogue; NC = 4, or 8 where the accumulators of C >= 256 output channels
-// would otherwise make the consumers the long pole).  The VALU and matrix pipes of a SIMD run concurrently for
-// different waves, so the stencil of chunk i overlaps the MFMAs of chunk i-1; halo tile, tap table and operand tile
-// are double-buffered in LDS, one barrier per chunk.
-template <typename T, int C, int NP, int NC>
-// C <= 64: cap registers at 85 (6 waves per SIMD) so THREE workgroups fit a CU (LDS allows it: 3 x 52 KiB); the few chunks
-// per tile at small C make pipeline fill/drain a third of a workgroup's life, and a third resident workgroup hides it
-// (A/B on one box: 369 -> 308 us at C=64, 1 M tokens).  C = 128 spills under that cap and stays at two.
-__global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void leff2_kernel(const Leff2Params p) {
-    constexpr int SR = 8 / NP;                    // rows of the column strip one producer thread convolves (NP = 4 or 8 producer waves)
+// ---- LDS-DMA helpers (gfx950 `buffer_load_dwordx4 ... lds` / `global_load_lds_dwordx4`) ---------------------------------
+// The halo tile and the tap table of a chunk go HBM/L2 -> LDS without passing through registers.  They are written as
+// inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front
+// of the next ds_read, which would serialise the stencil behind its own prefetch; an asm statement is invisible to that
+// pass, the waits are counted by hand below (one `s_waitcnt vmcnt(N)` per iteration, then the workgroup barrier).
+// Destination: LDS byte address M0 + lane * 16 (wave-uniform base, lane-linear image); source: per-lane.  M0 is saved and
+// restored inside the statement (the compiler owns it).  The leading s_nop covers the SGPR-written-by-VALU
+// (v_readfirstlane) -> VMEM-descriptor hazard, the one after s_mov the M0 -> LDS-DMA hazard.
+__device__ __forceinline__ void dma_buffer_to_lds(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_global_to_lds(const void* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(src) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+// XCD-aware workgroup -> tile order: consecutive workgroup ids go to different XCDs (id % 8, MI355X_MICROARCH.md), so give
+// every XCD one contiguous run of tiles (whole image rows / images): the halo pixels that neighbouring tiles share are then
+// served by that XCD's L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_tile(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// Wave-specialised kernel.  4*NPG PRODUCER waves (depthwise stencil + GELU on the VALU, and the LDS-DMA prefetch of the halo /
+// tap tiles) and NC CONSUMER waves (W2 fragments L2 -> registers, MFMAs, epilogue).  The hardware spreads the waves of a
+// workgroup over the 4 SIMDs, and the VALU and matrix pipes of a SIMD run concurrently for different waves, so the stencil
+// of interval i overlaps the MFMAs of interval i-1.  An interval = KC = 64*NPG hidden channels: producer group g (4 waves)
+// convolves channels [64g, 64g+64) of it.  NPG = 2 (8 stencil waves) is for grids that cannot put a second workgroup on a CU
+// (<= 256 tiles, or C = 512 whose consumers need the registers): two stencil waves per SIMD hide each other's LDS latency.
+// Halo / tap tiles: NBUF-deep ring in LDS filled by DMA NBUF-1 intervals ahead; operand tile: double buffered; one barrier
+// per interval.
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS>
+__global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const Leff2Params p) {
+    constexpr int NP = 4 * NPG;                   // producer waves
+    constexpr int SR = 2;                         // rows of the column strip one producer thread convolves
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
     constexpr int HID = 4 * C;
-    constexpr int NCH = HID / KC;                 // 64-channel chunks
+    constexpr int KC = KCW * NPG;                 // hidden channels per interval
+    constexpr int NIT = HID / KC;                 // intervals
+    static_assert(HID % KC == 0, "interval width");
     constexpr int HW_ = TW + 2, HT = (TH + 2) * HW_;  // 10 x 10 halo tile
-    constexpr int SH = KC * SZ + 16;              // LDS row stride, halo tile [HT][KC]
+    constexpr int PS = KCW * SZ;                  // LDS pixel stride of a group's halo tile [HT][64], unpadded (DMA image is lane-linear)
+    constexpr int CPP = PS / 16;                  // 16-byte pieces per pixel
+    constexpr int HGB = (HT * PS + 1023) / 1024 * 1024;   // bytes of one group's halo tile, in whole DMA instructions (1 KiB)
+    constexpr int NHG = HGB / 1024;               // DMA instructions per group halo tile
+    constexpr int TRB = KC * 4;                   // bytes of one tap-table row [KC] f32; table = 9 tap rows + 1 bias row
+    constexpr int TGB = (10 * TRB + 1023) / 1024 * 1024;
+    constexpr int NTI = TGB / 1024;
+    constexpr int NHI = NPG * NHG;                // halo DMA instructions per interval
+    constexpr int NI = NHI + NTI;                 // DMA instructions per interval
+    constexpr int NS = (NI + NP - 1) / NP;        // DMA slots per producer wave per interval (uniform: counted vmcnt)
+    constexpr int BUFB = NPG * HGB + TGB;         // bytes of one ring slot
     constexpr int SAT = KC * SZ + 16;             // LDS row stride, operand tile [BM][KC]
-    constexpr int CPP = KC * SZ / 16;             // 16-byte pieces per pixel per chunk
-    constexpr int NCT = NC * 64;                  // consumer threads
-    constexpr int NLD = (HT * CPP + NCT - 1) / NCT;   // staged 16-byte loads per consumer thread
+    constexpr int AT_BYTES = BM * SAT;
     constexpr int WN = (C / 16) < NC ? (C / 16) : NC, WM = NC / WN;   // consumer wave grid (pixels x out channels)
-    static_assert(WM <= 4 && NC * 64 >= 160, "consumer grid");
+    static_assert(WM <= 4, "consumer grid");
     constexpr int TMW = 4 / WM, TNW = (C / 16) / WN;               // 16x16 tiles per consumer wave
-    constexpr int HS_BYTES = HT * SH, AT_BYTES = BM * SAT, WL_BYTES = 10 * KC * 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Hs0 = smem;                             // halo tiles [2]
-    char* At0 = smem + 2 * HS_BYTES;              // operand tiles [2]
-    char* Wl0 = smem + 2 * HS_BYTES + 2 * AT_BYTES;   // taps [9][64] + bias [64], [2]
+    char* Ring = smem;                            // [NBUF] {halo tiles [NPG][HT][64] T, taps [10][KC] f32}
+    char* At0 = smem + NBUF * BUFB;               // operand tiles [2]
+    // last 1 KiB: landing zone of padding DMA slots (zeros)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool producer = wave < NP;
-    const int ct = tid - NP * 64;                 // consumer thread index (0..255) when !producer
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
-    const int bt = blockIdx.x;
+    const int bt = xcd_tile(blockIdx.x, gridDim.x);
     const int b = bt / (tiles_x * tiles_y), tr = bt - b * (tiles_x * tiles_y);
     const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
-    const T* h1 = reinterpret_cast<const T*>(p.h1) + (size_t)b * p.H * p.W * HID;
     const T* W2 = reinterpret_cast<const T*>(p.W2);
 
     Census census; census.begin();
     if (producer) {
-        // ------------------------------ producers: stencil ------------------------------------------
-        // a thread owns 8 channels x SR rows of one tile column; the 3 taps of a column come from the LDS tap
-        // table (same address for all pixels of a channel group: broadcast).  Measured alternatives that were
-        // slower: 8 producer waves (LDS-read bound, no gain) and wave-uniform taps via scalar loads (s_load
-        // shares lgkmcnt with the LDS reads and 72 taps exceed the SGPR budget: 2x slower).
-        const int cvec = tid & 7, sx = (tid >> 3) & 7, sy0 = (tid >> 6) * SR;
-        lds_barrier();                                                          // B0: halo(0), taps(0) staged
+        // ------------------------------ producers: DMA prefetch + stencil ---------------------------
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic region
+        const unsigned lds_dummy = lds0 + NBUF * BUFB + 2 * AT_BYTES;
+        // buffer descriptor over this image's h1: raw, 32-bit offsets, out-of-range lanes read 0 = the conv's zero padding
+        const char* img = reinterpret_cast<const char*>(p.h1) + (size_t)b * p.H * p.W * HID * SZ;
+        const unsigned long long ia = (unsigned long long)(uintptr_t)img;
+        const u32x4 rsrc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ia), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ia >> 32)) & 0xffffu,
+                            (unsigned)__builtin_amdgcn_readfirstlane(p.H * p.W * HID * SZ), 0x00020000u};
+        // this lane's source offset in each of the wave's DMA slots (slot s covers instruction wave + s*NP of the interval)
+        unsigned voff[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = wave + s * NP;
+            voff[s] = 0xffffff00u;                              // out of range -> zeros
+            if (idx < NHI) {
+                const int g = idx / NHG, q = (idx - g * NHG) * 64 + lane;    // piece q of group g's halo tile
+                const int hp = q / CPP, part = q - hp * CPP;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+                if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) voff[s] = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + part * 16);
+            }
+        }
+        auto issue = [&](int it) {                              // all DMA of interval `it` into ring slot it % NBUF
+            const unsigned slot = lds0 + (unsigned)(it % NBUF) * BUFB;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int idx = wave + s * NP;                  // wave-uniform
+                if (idx < NHI) {
+                    dma_buffer_to_lds(rsrc, voff[s], (unsigned)(it * KC * SZ), slot + (unsigned)idx * 1024u);
+                } else if (idx < NI) {
+                    const int q = (idx - NHI) * 64 + lane;      // piece q of the tap table: row q / (KC/4), 4 floats
+                    int row = q / (KC / 4);
+                    const int c4 = (q - row * (KC / 4)) * 4;
+                    row = row > 9 ? 9 : row;                    // pieces past the table re-read the bias row into the slack of the slot
+                    const float* src = (row < 9 ? p.w9 + (size_t)row * HID : p.bdw) + it * KC + c4;
+                    dma_global_to_lds(src, slot + NPG * HGB + (unsigned)(idx - NHI) * 1024u);
+                } else {
+                    dma_buffer_to_lds(rsrc, 0xffffff00u, 0u, lds_dummy);     // padding slot: keeps the per-wave DMA count uniform
+                }
+            }
+        };
+        const int grp = wave >> 2;                              // producer group
+        const int gt = tid & 255;                               // thread index within the group
+        const int cvec = gt & 7, sx = (gt >> 3) & 7, sy0 = (gt >> 6) * SR;
+#pragma unroll
+        for (int it = 0; it < NBUF - 1; ++it)
+            if (it < NIT) issue(it);
+        wait_dma<0>();
+        lds_barrier();                                                          // B0: intervals 0 .. NBUF-2 staged
         unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
 #pragma unroll 1
-        for (int i = 0; i <= NCH; ++i) {
-            if (i < NCH) {
-                const char* Hs = Hs0 + (i & 1) * HS_BYTES;
-                const float* Wl = reinterpret_cast<const float*>(Wl0 + (i & 1) * WL_BYTES);
-                char* At = At0 + (i & 1) * AT_BYTES;
+        for (int i = 0; i <= NIT; ++i) {
+            if (i + NBUF - 1 < NIT) issue(i + NBUF - 1);        // ring slot last read in iteration i-1
+            if (i < NIT) {
+                const char* Hs = Ring + (i % NBUF) * BUFB + grp * HGB;
+                const float* Wl = reinterpret_cast<const float*>(Ring + (i % NBUF) * BUFB + NPG * HGB) + grp * KCW;
+                char* At = At0 + (i & 1) * AT_BYTES + grp * KCW * SZ;
                 float o[SR][8];
 #pragma unroll
                 for (int r = 0; r < SR; ++r)
@@ -121,7 +199,7 @@ __global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void
 #pragma unroll
                     for (int r = -1; r <= SR; ++r) {      // halo row (sy0 + r + 1) feeds output rows r+1-ky
                         float f[8];
-                        cvt8<T>(Hs + ((sy0 + r + 1) * HW_ + sx + kx) * SH + cvec * 8 * SZ, f);
+                        cvt8<T>(Hs + ((sy0 + r + 1) * HW_ + sx + kx) * PS + cvec * 8 * SZ, f);
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky) {
                             const int orow = r + 1 - ky;
@@ -138,6 +216,8 @@ __global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void
                 }
             }
             t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
+            // interval i+1 must have landed before anyone passes the barrier; later intervals stay in flight
+            if (NBUF >= 3 && i + NBUF - 1 < NIT) wait_dma<(NBUF - 2) * NS>(); else wait_dma<0>();
             lds_barrier();
             t1 = __builtin_readcyclecounter(); tbar += t1 - t0; t0 = t1;
         }
@@ -148,45 +228,29 @@ __global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void
     // ---------------------------------- consumers ----------------------------------------------------
     const int cw = wave - NP;
     const int wm = cw / WN, wn = cw % WN;
-    // staging bookkeeping: which halo pixel / 16-byte piece each of this thread's loads covers
-    u32x4 stage[NLD];
-    int s_off[NLD];
-    bool s_ok[NLD];
-    int s_lds[NLD];
+    // W2 fragments through a buffer descriptor: ONE per-lane offset register (lane * fragment bytes) and scalar offsets per
+    // (tile, k-step) instead of a 64-bit pointer per tile -- the consumers of C >= 256 have no registers to spare
+    // WKS = k-steps of a sub-chunk whose fragments are prefetched together (across the barrier).  The f32 parity variants
+    // with 4 output tiles per wave have no registers for that (8 per fragment): they fetch one k-step at a time -- their
+    // exact-f32 MFMAs are 16x slower than bf16, so the exposed L2 round trip is a small part of the step.
+    constexpr int WKS = (SZ == 4 && TNW >= 4) ? 1 : 2;
+    Frag<T> wf[WKS][TNW];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(W2), 0, C * HID * SZ, 0x00020000);
+    const int wlane = lane * 8 * SZ;
+    auto w2_load = [&](int sub, int ks, int slot) {        // fragment-major W2: 1 KiB (bf16) contiguous per wave load; sub = 64-channel sub-chunk
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int idx = ct + NCT * i;
-        const int hp = idx / CPP, piece = idx - hp * CPP;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-        s_ok[i] = idx < HT * CPP && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;   // else zero = conv padding
-        const int cy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy), cx = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-        s_off[i] = (cy * p.W + cx) * HID + piece * (16 / SZ);
-        s_lds[i] = idx < HT * CPP ? hp * SH + piece * 16 : -1;
-    }
-    f32x4 wstage;
-    const int wl_row = ct >> 4, wl_c4 = (ct & 15) * 4;    // taps: 10 rows x 64 floats = 160 float4 (ct < 160)
-    auto stage_issue = [&](int ch) {                      // unconditional loads from clamped addresses
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) stage[i] = *reinterpret_cast<const u32x4*>(h1 + s_off[i] + ch * KC);
-        const int row = wl_row < 10 ? wl_row : 9;
-        const float* src = row < 9 ? p.w9 + (size_t)row * HID : p.bdw;
-        wstage = *reinterpret_cast<const f32x4*>(src + ch * KC + wl_c4);
+        for (int i = 0; i < TNW; ++i) {
+            const int soff = (((wn * TNW + i) * (HID / 32) + sub * 2 + ks) * 64) * 8 * SZ;     // wave-uniform
+            if constexpr (SZ == 2) {
+                wf[slot][i].v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, soff, 0));
+            } else {
+                wf[slot][i].lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane, soff, 0));
+                wf[slot][i].hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wlane + 16, soff, 0));
+            }
+        }
     };
-    auto stage_store = [&](int ch) {
-        char* Hs = Hs0 + (ch & 1) * HS_BYTES;
-#pragma unroll
-        for (int i = 0; i < NLD; ++i)
-            if (s_lds[i] >= 0) *reinterpret_cast<u32x4*>(Hs + s_lds[i]) = s_ok[i] ? stage[i] : u32x4{0, 0, 0, 0};
-        if (ct < 160) *reinterpret_cast<f32x4*>(Wl0 + (ch & 1) * WL_BYTES + (wl_row * KC + wl_c4) * 4) = wstage;
-    };
-    Frag<T> wf[2][TNW];
-    auto w2_issue = [&](int ch) {                          // fragment-major W2: 1 KiB contiguous per wave load
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < TNW; ++i)
-                load_frag(wf[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + ch * 2 + ks) * 64 + lane) * 8);
+    auto w2_issue = [&](int sub) {
+        if constexpr (WKS == 2) { w2_load(sub, 0, 0); w2_load(sub, 1, 1); }
     };
 
     f32x4 acc[TNW][TMW];
@@ -195,41 +259,38 @@ __global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void
 #pragma unroll
         for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Schedule of iteration j (producers run stencil(j) meanwhile):
-    //   (a) store halo/taps of chunk j+1 (loaded during iteration j-1) into buffer (j+1)&1 -- last read by
-    //       the producers in iteration j-1;  (b) issue the loads of chunk j+2 (a whole iteration to land:
-    //       raw barriers do not drain them);  (c) MFMAs of chunk j-1, then issue chunk j's W2 fragments.
-    stage_issue(0);
-    stage_store(0);
-    if (NCH > 1) stage_issue(1);
+    // iteration j: MFMAs of interval j-1 (operand tile written by the producers in iteration j-1), sub-chunk by sub-chunk;
+    // the W2 fragments of the next sub-chunk are requested as soon as the registers are free -- across the barrier between
+    // intervals, so their L2 round trip hides under the wait for the stencil
     w2_issue(0);
     lds_barrier();                                         // B0
-    unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
 #pragma unroll 1
-    for (int j = 0; j <= NCH; ++j) {
-        if (j + 1 < NCH) stage_store(j + 1);
-        if (j + 2 < NCH) stage_issue(j + 2);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j <= NIT; ++j) {
         if (j >= 1) {
             const char* At = At0 + ((j - 1) & 1) * AT_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                Frag<T> af[TMW];
+            for (int g = 0; g < NPG; ++g) {
+                const int sub = (j - 1) * NPG + g;
 #pragma unroll
-                for (int jj = 0; jj < TMW; ++jj)
-                    load_frag(af[jj], reinterpret_cast<const T*>(At + ((wm * TMW + jj) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
+                for (int ks = 0; ks < 2; ++ks) {
+                    if constexpr (WKS == 1) w2_load(sub, ks, 0);
+                    Frag<T> af[TMW];
 #pragma unroll
-                for (int ii = 0; ii < TNW; ++ii)
+                    for (int jj = 0; jj < TMW; ++jj)
+                        load_frag(af[jj], reinterpret_cast<const T*>(At + ((wm * TMW + jj) * 16 + fr) * SAT + (g * KCW + ks * 32 + fg * 8) * SZ));
+                    __builtin_amdgcn_sched_barrier(0);   // keep the operand reads of the next k-step behind these MFMAs (registers)
 #pragma unroll
-                    for (int jj = 0; jj < TMW; ++jj) mma16(acc[ii][jj], wf[ks][ii], af[jj]);
+                    for (int ii = 0; ii < TNW; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < TMW; ++jj) mma16(acc[ii][jj], wf[WKS == 2 ? ks : 0][ii], af[jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (sub + 1 < NIT * NPG) w2_issue(sub + 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (j < NCH) w2_issue(j);                      // fragments for the next iteration's MFMAs
         }
-        t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
         lds_barrier();
-        t1 = __builtin_readcyclecounter(); tbar += t1 - t0; t0 = t1;
     }
-    if (p.tbuf && lane == 0 && (bt & 63) == 0) { p.tbuf[((bt >> 6) * 16 + wave) * 4] = tw; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 1] = tbar; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 2] = producer; }
 
     // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
 #pragma unroll
@@ -244,32 +305,53 @@ __global__ __launch_bounds__((NP + NC) * 64, (C <= 64 ? 6 : (NP + NC) / 4)) void
             *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2);
         }
     }
-    if (ct == 0) {   // census entry written by the first consumer thread (thread 0 is a producer and has returned)
+    if (cw == 0 && lane == 0) {   // census entry written by the first consumer thread (thread 0 is a producer and has returned)
         Census c2 = census;
         if (p.tbuf) { unsigned long long* o = p.tbuf + 65536 + (size_t)bt * 8; o[0] = c2.t0; o[1] = __builtin_readcyclecounter(); o[2] = c2.r0; o[3] = wall_clock64();
             o[4] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); }
     }
 }
 
-template <typename T, int C>
-int launch_c(const Leff2Params& p, hipStream_t st) {
-    constexpr int SZ = sizeof(T);
-    // one producer (stencil) wave + one consumer (MFMA) wave per SIMD
-    // one producer (stencil) wave per SIMD; C >= 256 cannot fit two workgroups per CU anyway (accumulators), so it gets
-    // 8 consumer waves (half the accumulators, W2 fragments and MFMAs per wave): the consumers stop being the long pole
-    constexpr int NP = 4, NC = (SZ == 2 && C >= 256) ? 8 : 4;
-    constexpr int smem = 2 * 100 * (KC * SZ + 16) + 2 * 64 * (KC * SZ + 16) + 2 * 10 * KC * 4;
-    auto kern = leff2_kernel<T, C, NP, NC>;
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS>
+int launch_v(const Leff2Params& p, hipStream_t st) {
+    constexpr int SZ = sizeof(T), KC = KCW * NPG;
+    constexpr int HGB = (100 * KCW * SZ + 1023) / 1024 * 1024, TGB = (10 * KC * 4 + 1023) / 1024 * 1024;
+    constexpr int smem = NBUF * (NPG * HGB + TGB) + 2 * 64 * (KC * SZ + 16) + 1024;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    auto kern = leff2_kernel<T, C, NPG, NC, NBUF, WPS>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "leff2")) return rc;
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, NP, NC, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, 4 * NPG, NC, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((NP + NC) * 64), smem, st, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((4 * NPG + NC) * 64), smem, st, p);
     }
     return check_launch("leff2");
+}
+
+// Shape -> variant.  bf16: C <= 128: 8-wave workgroups small enough (51 KiB, <= 80 registers) for three per CU; C = 256: two per
+// CU (3-deep DMA ring, 128 registers); C = 512: 4 stencil + 8 MFMA waves, one workgroup per CU (the consumers' accumulators and
+// their W2 prefetch need 168 registers).  f32 (parity mode): one configuration per width.
+// UF_LEFF2_VARIANT=a selects the alternatives measured against these (A/B switch: 8 stencil waves working on 128-channel
+// intervals where a CU gets a single workgroup; two workgroups per CU at C = 128).
+template <typename T, int C>
+int launch_c(const Leff2Params& p, hipStream_t st) {
+    static const bool alt = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'a';
+    const int tiles = p.B * (p.H / 8) * (p.W / 8);
+    if constexpr (sizeof(T) == 2) {
+        if constexpr (C <= 64) return launch_v<T, C, 1, 4, 2, 6>(p, st);
+        else if constexpr (C == 128) return alt ? launch_v<T, C, 1, 4, 3, 4>(p, st) : launch_v<T, C, 1, 4, 2, 6>(p, st);
+        else if constexpr (C == 256) {
+            if (alt && tiles <= 256) return launch_v<T, C, 2, 8, 3, 4>(p, st);
+            return launch_v<T, C, 1, 4, 3, 4>(p, st);
+        } else return alt ? launch_v<T, C, 2, 8, 3, 4>(p, st) : launch_v<T, C, 1, 8, 3, 3>(p, st);
+    } else {
+        (void)tiles; (void)alt;
+        if constexpr (C <= 256) return launch_v<T, C, 1, 4, 2, 2>(p, st);
+        else return launch_v<T, C, 1, 4, 2, 2>(p, st);
+    }
 }
 
 template <typename T>

@@ -1,37 +1,39 @@
-"""Arbitrary-resolution inference wrapper: the pad -> forward -> crop -> clamp steps the reference's evaluation scripts
-put around ``Uformer.forward`` (test/test_sidd.py:79-92 ``expand2square``, :106-109; test/test_gopro_hide.py:77-103),
-kept on the device the image lives on.  Glue only (a handful of torch slice copies per image); the hot path is the model.
+"""Arbitrary-resolution inference.
+
+``restore``: exactly the steps the reference's evaluation scripts put around ``Uformer.forward`` -- ``expand2square`` to a square
+multiple of 128 (test/test_sidd.py:79-92), forward, ``masked_select`` crop, clamp (:106-109; test/test_gopro_hide.py:77-103) -- with
+the pad and the crop + clamp each ONE kernel on the device (``uf_expand2square``, ``uf_crop_clamp``); parity-exact with the
+reference pipeline.
+
+``restore_tiled``: a capability the reference does not have.  A 1280x720 frame padded to 1280x1280 computes 1.78x the pixels it
+needs; here the frame is covered by overlapping SQUARE tiles (the model needs H == W, multiples of 128) that are restored
+independently -- as one batch -- and cross-faded over the overlap.  It is an approximation of the full-frame result (a tile's
+border pixels see zero padding / a cut context instead of the neighbouring image), which is why it is opt-in and why the overlap is
+wide; ``restore`` stays the reference-exact path.
 """
 from __future__ import annotations
 
 import math
-from typing import Tuple
+from typing import List, Tuple
 
 import torch
+
+from . import ops
 
 Tensor = torch.Tensor
 
 
 def expand2square(timg: Tensor, factor: float = 128.0) -> Tuple[Tensor, Tensor]:
     """(B,C,h,w) -> zero canvas (B,C,X,X) with the image centred at ((X-h)//2, (X-w)//2), X = max(h,w) rounded up to a
-    multiple of ``factor`` (128 = 4 down-samplings x window 8), and the (B,1,X,X) mask of ones over the image.
-    Same arithmetic as the reference helper (which is written for B = 1), on ``timg``'s device."""
-    b, c, h, w = timg.shape
-    X = int(math.ceil(max(h, w) / float(factor)) * factor)
-    y0, x0 = (X - h) // 2, (X - w) // 2
-    img = torch.zeros(b, c, X, X, dtype=timg.dtype, device=timg.device)
-    mask = torch.zeros(b, 1, X, X, dtype=timg.dtype, device=timg.device)
-    img[:, :, y0:y0 + h, x0:x0 + w] = timg
-    mask[:, :, y0:y0 + h, x0:x0 + w] = 1
-    return img, mask
+    multiple of ``factor`` (128 = 4 down-samplings x window 8), and the (B,1,X,X) mask of ones over the image: the reference
+    helper (written for B = 1) for a batch, one kernel."""
+    return ops.expand2square(timg, factor, with_mask=True)
 
 
-def crop_to_mask(restored: Tensor, h: int, w: int) -> Tensor:
+def crop_to_mask(restored: Tensor, h: int, w: int, clamp: bool = False) -> Tensor:
     """Inverse of expand2square for the restored canvas: the (B,C,h,w) region the mask covers
-    (``torch.masked_select(restored, mask.bool()).reshape(1,3,h,w)`` in the reference, as a slice)."""
-    X = restored.shape[-1]
-    y0, x0 = (X - h) // 2, (X - w) // 2
-    return restored[:, :, y0:y0 + h, x0:x0 + w]
+    (``torch.masked_select(restored, mask.bool()).reshape(1,3,h,w)`` in the reference), optionally clamped to [0,1]."""
+    return ops.crop_clamp(restored, h, w, clamp)
 
 
 @torch.no_grad()
@@ -41,6 +43,61 @@ def restore(model, img: Tensor, factor: float = 128.0, clamp: bool = True) -> Te
     if img.dim() != 4:
         raise ValueError(f"restore expects (B,C,h,w), got {tuple(img.shape)}")
     h, w = img.shape[-2:]
-    padded, _ = expand2square(img, factor)
-    out = crop_to_mask(model(padded), h, w)
-    return torch.clamp(out, 0, 1) if clamp else out
+    padded, _ = ops.expand2square(img, factor, with_mask=False)
+    return ops.crop_clamp(model(padded), h, w, clamp)
+
+
+def _starts(n: int, tile: int, min_overlap: int) -> List[int]:
+    if n <= tile:
+        return [0]
+    k = max(2, math.ceil((n - min_overlap) / (tile - min_overlap)))
+    return sorted({round(i * (n - tile) / (k - 1)) for i in range(k)})
+
+
+@torch.no_grad()
+def restore_tiled(model, img: Tensor, tile: int = 768, min_overlap: int = 128, clamp: bool = True, max_batch: int = 8) -> Tensor:
+    """Overlapped-tile restoration of (B,3,h,w) images: square ``tile`` x ``tile`` windows (a multiple of 128) at evenly spaced
+    positions with at least ``min_overlap`` pixels in common, forwarded in batches of ``max_batch`` tiles, blended with a linear
+    ramp across each overlap.  An image that fits one tile takes the reference-exact ``restore`` path."""
+    if tile % 128:
+        raise ValueError("tile must be a multiple of 128")
+    B, C, h, w = img.shape
+    if h <= tile and w <= tile:
+        return restore(model, img, 128.0, clamp)
+    ys, xs = _starts(h, tile, min_overlap), _starts(w, tile, min_overlap)
+    acc = torch.zeros((B, C, h, w), dtype=torch.float32, device=img.device)
+    wsum = torch.zeros((1, 1, h, w), dtype=torch.float32, device=img.device)
+
+    def ramp(n: int, start: int, starts: List[int], size: int) -> Tensor:
+        """weight of a tile along one axis: 1 inside, linear ramps over the parts shared with the neighbouring tiles"""
+        wgt = torch.ones(size, device=img.device)
+        i = starts.index(start)
+        if i > 0:
+            ov = starts[i - 1] + tile - start
+            if ov > 0:
+                wgt[:ov] = (torch.arange(ov, device=img.device) + 0.5) / ov
+        if i + 1 < len(starts):
+            ov = start + tile - starts[i + 1]
+            if ov > 0:
+                wgt[size - ov:size] = wgt[size - ov:size] * (1 - (torch.arange(ov, device=img.device) + 0.5) / ov)
+        return wgt
+
+    jobs = [(y, x) for y in ys for x in xs]
+    for j0 in range(0, len(jobs), max(1, max_batch // B)):
+        chunk = jobs[j0:j0 + max(1, max_batch // B)]
+        tiles = []
+        for (y, x) in chunk:
+            th, tw = min(tile, h - y), min(tile, w - x)
+            t = img[:, :, y:y + th, x:x + tw]
+            if th < tile or tw < tile:                       # image smaller than a tile along this axis: zero-pad at the far side
+                t = torch.nn.functional.pad(t, (0, tile - tw, 0, tile - th))
+            tiles.append(t)
+        out = model(torch.cat(tiles, 0).contiguous())
+        for k, (y, x) in enumerate(chunk):
+            th, tw = min(tile, h - y), min(tile, w - x)
+            wy, wx = ramp(h, y, ys, th), ramp(w, x, xs, tw)
+            wgt = (wy[:, None] * wx[None, :])[None, None]
+            acc[:, :, y:y + th, x:x + tw] += out[k * B:(k + 1) * B, :, :th, :tw].float() * wgt
+            wsum[:, :, y:y + th, x:x + tw] += wgt
+    res = acc / wsum
+    return torch.clamp(res, 0, 1) if clamp else res

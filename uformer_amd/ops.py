@@ -408,3 +408,135 @@ def output_proj(x: Tensor, w: Tensor, bias: Tensor, B: int, H: int, W: int, img:
                                                   _ptr(img), _ptr(out), B, H, W, C2, int(img is not None), _stream()),
                    "uf_output_proj_fwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# training-step tail, metrics, arbitrary-resolution wrapper, input pipeline
+# ---------------------------------------------------------------------------------------
+def _ws(nbytes: int, device) -> Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def charbonnier(y: Tensor, target: Tensor, eps: float = 1e-3, with_grad: bool = True, grad_scale: float = 1.0):
+    """CharbonnierLoss.forward (losses.py:41-52) and d loss / d y in ONE pass: returns (loss f32 0-dim tensor, dy or None)."""
+    _dev(y, target)
+    y, target = _c(y, torch.float32), _c(target, torch.float32)
+    n = y.numel()
+    loss = torch.empty(1, dtype=torch.float32, device=y.device)
+    dy = torch.empty_like(y) if with_grad else None
+    lib = _lib.load()
+    nbytes = lib.uf_charbonnier_workspace_bytes(n)
+    ws = _ws(nbytes, y.device)
+    with torch.cuda.device(y.device):
+        _lib.check(lib.uf_charbonnier_fwd_bwd(_ptr(y), _ptr(target), _ptr(dy), _ptr(loss), n, eps, grad_scale, _ptr(ws), nbytes, _stream()),
+                   "uf_charbonnier_fwd_bwd")
+    return loss.reshape(()), dy
+
+
+def adamw_step(params, grads, exp_avg, exp_avg_sq, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.02,
+               step: int = 1, grad_scale: float = 1.0) -> None:
+    """One torch.optim.AdamW step over lists of f32 tensors, in place (train/train_denoise.py:77).  ``step`` counts from 1."""
+    import ctypes as C
+    n = len(params)
+    if not (len(grads) == len(exp_avg) == len(exp_avg_sq) == n):
+        raise UformerHipError("adamw_step: list lengths differ")
+    if n == 0:
+        return
+    dev = _dev(*params, *grads, *exp_avg, *exp_avg_sq)
+    for group in (params, grads, exp_avg, exp_avg_sq):
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise UformerHipError("adamw_step: tensors must be contiguous float32")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+    numel = (C.c_longlong * n)(*[p.numel() for p in params])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().uf_adamw_step(arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, n, lr, betas[0], betas[1], eps,
+                                             weight_decay, int(step), grad_scale, _stream()), "uf_adamw_step")
+
+
+def batch_mse(a: Tensor, b: Tensor, clamp01: bool = True) -> Tensor:
+    """Per-image mean squared difference of (B,C,H,W) f32 images, clamped to [0,1] first (myPSNR, utils/image_utils.py:40-44)."""
+    _dev(a, b)
+    a, b = _c(a, torch.float32), _c(b, torch.float32)
+    if a.shape != b.shape or a.dim() != 4:
+        raise UformerHipError(f"batch_mse: shapes {tuple(a.shape)} / {tuple(b.shape)}")
+    B, Cc, H, W = a.shape
+    out = torch.empty(B, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    nbytes = lib.uf_image_metric_workspace_bytes(B, Cc, H, W)
+    ws = _ws(nbytes, a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.uf_batch_mse(_ptr(a), _ptr(b), _ptr(out), B, Cc, H, W, int(clamp01), _ptr(ws), nbytes, _stream()), "uf_batch_mse")
+    return out
+
+
+def batch_ssim(a: Tensor, b: Tensor) -> Tensor:
+    """Per-image SSIM of (B,C,H,W) f32 images in [0,1] as calculate_ssim computes it (utils/caculate_psnr_ssim.py:35-81)."""
+    _dev(a, b)
+    a, b = _c(a, torch.float32), _c(b, torch.float32)
+    if a.shape != b.shape or a.dim() != 4:
+        raise UformerHipError(f"batch_ssim: shapes {tuple(a.shape)} / {tuple(b.shape)}")
+    B, Cc, H, W = a.shape
+    out = torch.empty(B, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    nbytes = lib.uf_image_metric_workspace_bytes(B, Cc, H, W)
+    ws = _ws(nbytes, a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.uf_batch_ssim(_ptr(a), _ptr(b), _ptr(out), B, Cc, H, W, _ptr(ws), nbytes, _stream()), "uf_batch_ssim")
+    return out
+
+
+def expand2square(img: Tensor, factor: float = 128.0, with_mask: bool = True):
+    """test/test_sidd.py:79-92 for a batch: (B,C,h,w) -> zero canvas (B,C,X,X) with the image centred, + (B,1,X,X) mask."""
+    import math
+    _dev(img)
+    img = _c(img, torch.float32)
+    B, Cc, h, w = img.shape
+    X = int(math.ceil(max(h, w) / float(factor)) * factor)
+    canvas = torch.empty((B, Cc, X, X), dtype=torch.float32, device=img.device)
+    mask = torch.empty((B, 1, X, X), dtype=torch.float32, device=img.device) if with_mask else None
+    with torch.cuda.device(img.device):
+        _lib.check(_lib.load().uf_expand2square(_ptr(img), _ptr(canvas), _ptr(mask), B, Cc, h, w, X, _stream()), "uf_expand2square")
+    return canvas, mask
+
+
+def crop_clamp(canvas: Tensor, h: int, w: int, clamp: bool = True) -> Tensor:
+    """masked_select crop of the restored canvas back to (B,C,h,w) + clamp to [0,1] (test/test_sidd.py:108-109)."""
+    _dev(canvas)
+    canvas = _c(canvas, torch.float32)
+    B, Cc, X, X2 = canvas.shape
+    if X != X2:
+        raise UformerHipError("crop_clamp: square canvas expected")
+    out = torch.empty((B, Cc, h, w), dtype=torch.float32, device=canvas.device)
+    with torch.cuda.device(canvas.device):
+        _lib.check(_lib.load().uf_crop_clamp(_ptr(canvas), _ptr(out), B, Cc, h, w, X, int(clamp), _stream()), "uf_crop_clamp")
+    return out
+
+
+def crop_augment(frames: Tensor, meta: Tensor, ps: int, hwc: bool = False) -> Tensor:
+    """frames: (N,3,H,W) or (N,H,W,3) (hwc) uint8 / f32 on the GPU; meta int32 (B,4) = [frame index, r0, c0, transform 0..7]
+    -> (B,3,ps,ps) f32 patches (dataset/dataset_denoise.py:54-70; uint8 is divided by 255 like load_img)."""
+    _dev(frames, meta)
+    if frames.dtype not in (torch.uint8, torch.float32):
+        raise UformerHipError("crop_augment: frames must be uint8 or float32")
+    frames, meta = _c(frames), _c(meta, torch.int32)
+    N = frames.shape[0]
+    H, W = (frames.shape[1], frames.shape[2]) if hwc else (frames.shape[2], frames.shape[3])
+    B = meta.shape[0]
+    out = torch.empty((B, 3, ps, ps), dtype=torch.float32, device=frames.device)
+    with torch.cuda.device(frames.device):
+        _lib.check(_lib.load().uf_crop_augment(_ptr(frames), int(frames.dtype == torch.uint8), int(hwc), _ptr(out), _ptr(meta), B, N, H, W, ps,
+                                               _stream()), "uf_crop_augment")
+    return out
+
+
+def mixup(x: Tensor, lam: Tensor, perm: Tensor) -> Tensor:
+    """lam[b] x[b] + (1 - lam[b]) x[perm[b]] (utils/dataset_utils.py:44-53)."""
+    _dev(x, lam, perm)
+    x = _c(x, torch.float32)
+    B = x.shape[0]
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_mixup(_ptr(x), _ptr(out), _ptr(_c(lam.reshape(-1), torch.float32)), _ptr(_c(perm, torch.int32)), B,
+                                        x.numel() // B, _stream()), "uf_mixup")
+    return out
