@@ -178,6 +178,14 @@ int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, int B, int H,
                        const float* user_mask, int n_mask, uf_dtype dtype, void* ws,
                        size_t ws_bytes, void* stream);
 
+/* ---- a11 in train() mode: the same two fused kernels with timm's DropPath applied to each residual branch:
+ * x = x + drop_attn[b] * attention_branch;  x = x + drop_leff[b] * LeFF_branch  (model.py:986-987; scales = bernoulli(keep)/keep
+ * per image, f32[B] on the device, NULL = 1).  The caller keeps a copy of x before the call: it is all the backward needs
+ * (everything else is recomputed, uformer_amd/train.py). */
+int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
+                             const float* drop_attn, const float* drop_leff, uf_dtype dtype, void* ws,
+                             size_t ws_bytes, void* stream);
+
 /* ---- a12: Downsample.forward (Conv2d k4 s2 p1 on tokens, model.py:739-746) -----------------
  * x f32[B][H][W] rows of C (stride ld_x); w T[2C][16C] with k = (ky*4+kx)*C + c; out f32
  * [B][H/2][W/2] rows of 2C (stride ld_o). */
@@ -233,6 +241,25 @@ int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const 
 size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);
 int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C,
                        uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- a15: reductions and patch gathers of the backward (no ATen glue) -------------------------------------------------------
+ * out f32[N] = sum over the M rows of X T[M][ld]: the modulator gradient (model.py:966-969: the (64,C) table is added to every
+ * window, so its gradient is the sum of d(xn) over windows: M = n_windows, N = 64*C) and bias-like column sums.  Fixed order. */
+size_t uf_rows_sum_workspace_bytes(int M, int N);
+int uf_rows_sum(const void* X, int ld, float* out, int M, int N, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* relative_position_bias_table gradient f32[225][heads] from the dense bias gradient f32[heads][64][64] that
+ * uf_window_attention_bwd returns: the transpose of the gather table[index] (model.py:500-502), as a gather over the pairs
+ * of each table entry instead of a scatter-add with atomics. */
+int uf_rpb_table_grad(const float* dbias_dense, float* dtable, int heads, void* stream);
+/* patch matrices of the strided convolutions (Downsample k4 s2 p1, stem / head k3 s1 p1; model.py:734,785,817) for their
+ * weight and input gradients through uf_linear_wgrad / uf_linear_fwd:
+ *   cols T[B*Ho*Wo][ldc], column (ky*k + kx)*Cin + c = x[b][oy*s + ky - pad][ox*s + kx - pad][c], zero outside and in the
+ *   padding columns; x f32 token rows (stride ld_x) or, nchw = 1, (B,Cin,H,W) planes.
+ *   uf_col2im is the transpose (gather form, fixed order): dx (+)= sum of the matching dcols entries; accumulate = 1 adds to dx. */
+int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, int H, int W, int Cin, int k, int stride, int pad,
+              int nchw, uf_dtype dtype, void* stream);
+int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B, int H, int W, int Cin, int k, int stride, int pad,
+              int nchw, int accumulate, uf_dtype dtype, void* stream);
 
 /* ---- f-2: training-step tail ------------------------------------------------------------------------------
  * CharbonnierLoss.forward + its gradient in one pass (losses.py:41-52; criterion of train/train_denoise.py:164,181):

@@ -17,7 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from uformer_amd import dist as ud  # noqa: E402
+from uformer_amd import losses as ul  # noqa: E402
 from uformer_amd import model as um  # noqa: E402
+from uformer_amd import optim as uo  # noqa: E402
 from uformer_amd import spec  # noqa: E402
 
 
@@ -38,18 +40,18 @@ def main():
                    dd_in=cfg.dd_in, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
     m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
     m = m.cuda().train()
-    opt = torch.optim.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77
+    opt = uo.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77, on uf_adamw_step
+    criterion = ul.CharbonnierLoss()                                                          # losses.py:41-52, on uf_charbonnier_fwd_bwd
     x = spec.synth_input(a.batch, a.img, a.img, 1234 + 2 * rank).cuda()            # per-GPU batch (weak scaling)
     target = spec.synth_input(a.batch, a.img, a.img, 1235 + 2 * rank).cuda()
     reduce_grads = ud.GradientAllReduce(list(m.parameters()))
 
     def step():
         opt.zero_grad(set_to_none=True)
-        d = m(x) - target
-        loss = torch.mean(torch.sqrt(d * d + 1e-6))                                  # CharbonnierLoss (losses.py:41-52)
+        loss = criterion(m(x), target)
         loss.backward()
         reduce_grads()                                                               # no-op on one GPU
-        opt.step()
+        opt.step(grad_scale=1.0)
         return loss
 
     for _ in range(a.warmup):

@@ -91,21 +91,21 @@ def test_shard_batch():
         assert max(sizes) - min(sizes) <= 1
 
 
-def test_infer_wrapper_matches_reference_padding():
-    """uformer_amd.infer.expand2square / crop_to_mask == the reference helper (test/test_sidd.py:79-92) restated in the
-    oracle, including the masked_select crop, for odd sizes; restore() = pad -> model -> crop -> clamp."""
+def test_infer_wrapper_has_no_cpu_path_and_tiles_cover_the_frame():
+    """uformer_amd.infer pads / crops with kernels (tests/test_gpu_tail.py checks them against the reference helper restated in
+    the oracle); on CPU tensors it raises instead of falling back.  The tile placement of restore_tiled is host logic: tiles
+    cover the frame, start and end on it, and overlap by at least the requested margin."""
+    import pytest
     import torch
-    from oracle import uformer_oracle as O
     from uformer_amd import infer
-    for (h, w) in ((200, 136), (72, 128), (128, 128), (130, 250)):
-        img = torch.rand(1, 3, h, w)
-        a, ma = infer.expand2square(img, 128.0)
-        b, mb = O.expand2square(img, 128.0)
-        assert torch.equal(a, b) and torch.equal(ma, mb)
-        crop = torch.masked_select(a, ma.bool()).reshape(1, 3, h, w)
-        assert torch.equal(infer.crop_to_mask(a, h, w), crop) and torch.equal(crop, img)
-    out = infer.restore(lambda x: x * 2.0 - 0.25, torch.rand(2, 3, 40, 24), factor=16.0)
-    assert out.shape == (2, 3, 40, 24) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    from uformer_amd._lib import UformerHipError
+    with pytest.raises(UformerHipError):
+        infer.expand2square(torch.rand(1, 3, 40, 24), 16.0)
+    for (n, tile, ov) in ((1280, 768, 128), (720, 768, 128), (2000, 512, 128), (769, 768, 256), (1536, 768, 0)):
+        st = infer._starts(n, tile, ov)
+        assert st[0] == 0 and (n <= tile or st[-1] + tile == n)
+        for a, b in zip(st, st[1:]):
+            assert 0 < b - a <= tile - ov, (n, tile, ov, st)
 
 
 def test_fragment_major_packing_formula_cpu():

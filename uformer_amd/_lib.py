@@ -75,10 +75,16 @@ SIGNATURES = {
     "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
     "uf_leff_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, I, P, c_size_t, P]),
     "uf_lewin_block_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
+    "uf_lewin_block_train_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, P, I, P, c_size_t, P]),
     "uf_downsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
     "uf_upsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "uf_input_proj_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "uf_output_proj_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),
+    "uf_rows_sum_workspace_bytes": (c_size_t, [I, I]),
+    "uf_rows_sum": (I, [P, I, P, I, I, I, P, c_size_t, P]),
+    "uf_rpb_table_grad": (I, [P, P, I, P]),
+    "uf_im2col": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
+    "uf_col2im": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "uf_charbonnier_workspace_bytes": (c_size_t, [C.c_longlong]),
     "uf_charbonnier_fwd_bwd": (I, [P, P, P, P, C.c_longlong, C.c_float, C.c_float, P, c_size_t, P]),
     "uf_adamw_step": (I, [P, P, P, P, P, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, C.c_double, P]),

@@ -38,6 +38,7 @@ struct AttnBlkParams {
     const float* gamma2; const float* beta2;   // phase 3 (h1 != NULL): norm2, linear1 (fragment-major T[4C][C]), its bias
     const void* W1; const float* b1;
     void* h1;                              // T[B*H*W][4C] or NULL
+    const float* drop;                     // training: per-image DropPath scale of this branch (bernoulli(keep)/keep, model.py:986) or NULL
     int n_windows, H, W, shift;
     float qscale;
     unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
@@ -47,7 +48,10 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 // weight-fragment ring depths (k-steps of L2 -> register loads in flight) of the three GEMM phases at C >= 256
 #ifndef UF_LN_ROTATE
-#define UF_LN_ROTATE 1
+#define UF_LN_ROTATE 0
+#endif
+#ifndef UF_LN_WIDE
+#define UF_LN_WIDE 1
 #endif
 #ifndef UF_QKV_RING
 #define UF_QKV_RING 3
@@ -156,7 +160,7 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
 }
 
 template <typename T, int C, int NT>
-__global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p) {
+__global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2)) void attn_block_kernel(const AttnBlkParams p) {
     constexpr int SZ = sizeof(T);
     constexpr int WAVES = NT / 64;
     constexpr int HEADS = C / 32;
@@ -183,9 +187,25 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
     stamp(0);
     Census census; census.begin();
 
+    // The small tables of the later phases (relative-position bias, q/k/v and proj biases) are REQUESTED here, all at once and
+    // unconditionally (clamped index), and stored to LDS after phase 0.  They used to be copied by a load -> store loop behind
+    // phase 0: 11 dependent L2 round trips per thread at C >= 256 -- 20 K of the 27 K cycles the stamps charged to "LN".
+    constexpr int NTABV = HEADS * 225 + 4 * C, NTAB = (NTABV + NT - 1) / NT;
+    float tabv[NTAB];
+#pragma unroll
+    for (int k = 0; k < NTAB; ++k) {
+        int i = tid + k * NT;
+        i = i < NTABV ? i : NTABV - 1;
+        const float* src = i < HEADS * 225 ? p.rpb_tab + i : (i < HEADS * 225 + 3 * C ? p.bqkv + (i - HEADS * 225) : p.bp + (i - HEADS * 225 - 3 * C));
+        tabv[k] = *src;
+    }
     // ---------------- phase 0: LN1 (+gather, +modulator) -> Xn --------------------------------------
     {
-        constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
+        // lanes per row: 16 channels (four 16-byte pieces) per lane where the row is long enough.  The per-ROW work -- two
+        // cross-lane reductions, the square root and the division -- is what this phase spends its VALU time on (measured:
+        // 27 K cycles at C = 256 with 64 lanes x 4 channels per row, against 4 K for the loads alone), and it is paid per lane:
+        // 16 lanes x 16 channels cut the rows a thread owns from 16 to 4 and each reduction from 6 steps to 4.
+        constexpr int LPR = UF_LN_WIDE ? ((C / 16) < 8 ? 8 : (C / 16)) : ((C / 4) < 64 ? (C / 4) : 64);
         constexpr int V4 = C / (4 * LPR);
         constexpr int RPP = NT / LPR;
         constexpr int NP = 64 / RPP;
@@ -221,7 +241,9 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
                     sq += (v[u][i][0] * v[u][i][0] + v[u][i][1] * v[u][i][1]) + (v[u][i][2] * v[u][i][2] + v[u][i][3] * v[u][i][3]);
                 }
                 sq = allreduce<RedSum, LPR>(sq);
-                const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
+                float rstd;
+                if constexpr (SZ == 2) rstd = __builtin_amdgcn_rsqf(sq * (1.0f / C) + 1e-5f);   // 1 ulp: far under the bf16 rounding of the result
+                else rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {
                     const int c = (i * LPR + sub) * 4;
@@ -232,8 +254,12 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             }
         }
     }
-    for (int i = tid; i < HEADS * 225; i += NT) Tab[i] = p.rpb_tab[i] * LOG2E;   // scores live in the log2 domain (see softmax)
-    for (int i = tid; i < 4 * C; i += NT) Bq[i] = i < 3 * C ? p.bqkv[i] : p.bp[i - 3 * C];
+#pragma unroll
+    for (int k = 0; k < NTAB; ++k) {              // requested before phase 0 (see there); Tab | Bq are contiguous in LDS
+        const int i = tid + k * NT;
+        if (i < HEADS * 225) Tab[i] = tabv[k] * LOG2E;   // scores live in the log2 domain (see softmax)
+        else if (i < HEADS * 225 + 4 * C) Bq[i - HEADS * 225] = tabv[k];
+    }
     stamp(1);
     lds_barrier();
     stamp(2);
@@ -476,6 +502,7 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(7);
+        const float dscale = p.drop ? p.drop[geo.img] : 1.0f;   // DropPath: x + scale_b * branch (timm, train mode only)
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
             float* xr = xrow[j];
@@ -483,8 +510,8 @@ __global__ __launch_bounds__(NT, 2) void attn_block_kernel(const AttnBlkParams p
             for (int i = 0; i < TNW; ++i) {
                 const int n = (wn * TNW + i) * 16 + fg * 4;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(Bq + 3 * C + n);
-                if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b);   // the block's new rows stay in registers
-                else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b);
+                if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b) * dscale;   // the block's new rows stay in registers
+                else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b) * dscale;
                 *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
             }
         }
@@ -580,8 +607,9 @@ bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_
     return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
 }
 
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st) {
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st, const float* drop) {
     AttnBlkParams p{};
+    p.drop = drop;
     p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
     p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;

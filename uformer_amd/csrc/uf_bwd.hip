@@ -136,14 +136,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// out[j] = sum_{p < P} partial[p * stride + j], j < n: one thread per output, partials added in index order
-__global__ void column_sum_kernel(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
+// out[j] = sum_{p < P} partial[p * stride + j], j < n.  A workgroup owns 32 columns; 8 "p-lanes" per column each add every 8th
+// partial in index order (loads of a wave: 32 consecutive columns = 128 B per p), then the 8 lane sums are added in lane order
+// through LDS.  The order depends only on P: bit-reproducible.  (The first version gave every column ONE thread that walked all P
+// partials -- up to 32 K dependent steps on a handful of threads; it was 65 % of the GPU time of a training step.)
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n) {
+    __shared__ float sh[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + col;
     float s = 0.f;
-    for (int p = 0; p < P; ++p) s += partial[(size_t)p * stride + j];
-    out[j] = s;
+    if (j < n) {
+        const float* src = partial + j;
+        int p = pl;
+        for (; p + 24 < P; p += 32) {       // four independent loads in flight per thread
+            const float a = src[(size_t)p * stride], b = src[(size_t)(p + 8) * stride], c = src[(size_t)(p + 16) * stride], d = src[(size_t)(p + 24) * stride];
+            s = (((s + a) + b) + c) + d;
+        }
+        for (; p < P; p += 8) s += src[(size_t)p * stride];
+    }
+    sh[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && j < n) {
+        float t = sh[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += sh[k][col];
+        out[j] = t;
+    }
 }
+constexpr int COLSUM_COLS = 32;   // columns per workgroup of column_sum_kernel
 
 constexpr int LN_BWD_MAX_BLOCKS = 512;
 
@@ -212,15 +232,28 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restric
         for (int i = 0; i < N; ++i) out[t * N + i] = acc[t][i];
 }
 
-// dw9[t][c] (t < 9) and dbias[c] (t == 9) = sum over the threads j = cg, cg + cv, ... of partial[j][t][c % N]
-__global__ void dwconv3x3_wgrad_finalize(const float* __restrict__ partial, long long nthreads, int cv, int N, float* __restrict__ dw9,
-                                         float* __restrict__ dbias, int C) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;   // over 10 * C outputs
-    if (j >= 10 * C) return;
-    const int t = j / C, c = j % C, cg = c / N, i = c % N;
+// dw9[t][c] (t < 9) and dbias[c] (t == 9) = sum over the threads j = cg, cg + cv, ... of partial[j][t][c % N].  32 outputs per
+// workgroup, 8 p-lanes per output (every 8th contributing thread, in order), lane sums added in lane order: fixed order.
+__global__ __launch_bounds__(256) void dwconv3x3_wgrad_finalize(const float* __restrict__ partial, long long nthreads, int cv, int N, float* __restrict__ dw9,
+                                                               float* __restrict__ dbias, int C) {
+    __shared__ float sh[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + col;   // over 10 * C outputs
     float s = 0.f;
-    for (long long th = cg; th < nthreads; th += cv) s += partial[(size_t)th * 10 * N + t * N + i];
-    if (t < 9) dw9[(size_t)t * C + c] = s; else dbias[c] = s;
+    int t = 0, c = 0;
+    if (j < 10 * C) {
+        t = j / C; c = j % C;
+        const int cg = c / N, i = c % N;
+        for (long long th = cg + (long long)pl * cv; th < nthreads; th += 8LL * cv) s += partial[(size_t)th * 10 * N + t * N + i];
+    }
+    sh[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && j < 10 * C) {
+        float r = sh[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r += sh[k][col];
+        if (t < 9) dw9[(size_t)t * C + c] = r; else dbias[c] = r;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -563,8 +596,8 @@ extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, co
 #undef UF_LNB_CASE
     int rc = check_launch("layernorm_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial, slots, (size_t)2 * C, dgamma, C);
-    hipLaunchKernelGGL(column_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, st, partial + C, slots, (size_t)2 * C, dbeta, C);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial, slots, (size_t)2 * C, dgamma, C);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial + C, slots, (size_t)2 * C, dbeta, C);
     return check_launch("layernorm_bwd_finalize");
 }
 
@@ -594,7 +627,7 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     else hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (const float*)dc, (float*)ws, B, H, W, C);
     int rc = check_launch("dwconv3x3_wgrad");
     if (rc) return rc;
-    hipLaunchKernelGGL(dwconv3x3_wgrad_finalize, dim3((10 * C + 255) / 256), dim3(256), 0, st, (const float*)ws, (long long)blocks * 256, cv, N, dw9, dbias, C);
+    hipLaunchKernelGGL(dwconv3x3_wgrad_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, (long long)blocks * 256, cv, N, dw9, dbias, C);
     return check_launch("dwconv3x3_wgrad_finalize");
 }
 
@@ -636,8 +669,8 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     int rc = check_launch("linear_wgrad");
     if (rc) return rc;
     const int nk = N * K;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((nk + 255) / 256), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
-    if (db) hipLaunchKernelGGL(column_sum_kernel, dim3((N + 255) / 256), dim3(256), 0, st, ws_b, S, (size_t)N, db, N);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((nk + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
+    if (db) hipLaunchKernelGGL(column_sum_kernel, dim3((N + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_b, S, (size_t)N, db, N);
     return check_launch("linear_wgrad_finalize");
 }
 
@@ -691,6 +724,154 @@ extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void*
     int rc = check_launch("window_attn_bwd");
     if (rc) return rc;
     const int nb = heads * 4096;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)ws, G, (size_t)nb, dbias, nb);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((nb + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)ws, G, (size_t)nb, dbias, nb);
     return check_launch("window_attn_bwd_finalize");
+}
+
+// ===============================================================================================================================
+// Reductions / patch gathers of the training path that used to be ATen glue: the relative-position
+// bias-table gradient (index_add_), the modulator gradient (sum over windows) and the im2col / col2im of the strided
+// convolutions (torch unfold / fold).  All deterministic.
+// ===============================================================================================================================
+namespace uf {
+namespace {
+
+// partial[p][n] = sum over rows m = p, p + P, ... of X[m][n]  (then column_sum_kernel over p)
+template <typename T>
+__global__ __launch_bounds__(256) void rows_partial_kernel(const T* __restrict__ X, int ld, float* __restrict__ partial, int M, int N, int P) {
+    constexpr int V = Vec<T>::N;
+    const int nv = N / V;
+    const int j = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+    if (j >= nv) return;
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int m = p; m < M; m += P) {
+        float f[V];
+        Vec<T>::load(X + (size_t)m * ld + (size_t)j * V, f);
+#pragma unroll
+        for (int i = 0; i < V; ++i) acc[i] += f[i];
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) partial[(size_t)p * N + (size_t)j * V + i] = acc[i];
+}
+
+// dtable[e][h] = sum of dbias[h][i][j] over the (i, j) with relative_position_index[i][j] == e, e = (dy+7)*15 + (dx+7)
+// (model.py:467-477, :500-502): for a fixed (dy, dx) the pairs are yi in [max(0,dy), min(8,8+dy)), xi likewise -- walked in
+// row-major order, one thread per table entry and head.
+__global__ void rpb_table_grad_kernel(const float* __restrict__ dbias, float* __restrict__ dtable, int heads) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 225 * heads) return;
+    const int e = t / heads, h = t - e * heads;
+    const int dy = e / 15 - 7, dx = e % 15 - 7;
+    float s = 0.f;
+    for (int yi = (dy > 0 ? dy : 0); yi < (dy < 0 ? 8 + dy : 8); ++yi)
+        for (int xi = (dx > 0 ? dx : 0); xi < (dx < 0 ? 8 + dx : 8); ++xi) {
+            const int i = yi * 8 + xi, j = (yi - dy) * 8 + (xi - dx);
+            s += dbias[((size_t)h * 64 + i) * 64 + j];
+        }
+    dtable[(size_t)e * heads + h] = s;
+}
+
+// cols[m][(ky*k + kx)*Cin + c] = x[b][oy*s + ky - pad][ox*s + kx - pad][c] (0 outside the map), m = (b*Ho + oy)*Wo + ox; columns
+// [k*k*Cin, ldc) are zero.  x: f32 token rows (stride ld_x) or NCHW planes.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ x, int ld_x, T* __restrict__ cols, int ldc, int B, int H, int W, int Cin, int k,
+                                                     int stride, int pad, int Ho, int Wo, int nchw) {
+    const long long total = (long long)B * Ho * Wo * ldc;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int col = (int)(t % ldc);
+        const long long m = t / ldc;
+        float v = 0.f;
+        if (col < k * k * Cin) {
+            const int c = col % Cin, tap = col / Cin, ky = tap / k, kx = tap - ky * k;
+            const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = nchw ? x[(((size_t)b * Cin + c) * H + iy) * W + ix] : x[((size_t)(b * H + iy) * W + ix) * ld_x + c];
+        }
+        store1(cols + t, v);
+    }
+}
+
+// dx[b][y][x][c] (+)= sum over the taps (ky, kx) whose output pixel oy = (y + pad - ky) / stride, ox = ... is integral and inside:
+// dcols[(b*Ho + oy)*Wo + ox][(ky*k + kx)*Cin + c].  Gather form: one thread per input element, taps in (ky, kx) order.
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcols, int ldc, float* __restrict__ dx, int ld_dx, int B, int H, int W, int Cin, int k,
+                                                     int stride, int pad, int Ho, int Wo, int nchw, int accumulate) {
+    const long long total = (long long)B * H * W * Cin;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int c, xx, yy, b;
+        if (nchw) { xx = (int)(t % W); yy = (int)((t / W) % H); c = (int)((t / ((long long)W * H)) % Cin); b = (int)(t / ((long long)W * H * Cin)); }
+        else { c = (int)(t % Cin); xx = (int)((t / Cin) % W); yy = (int)((t / ((long long)Cin * W)) % H); b = (int)(t / ((long long)Cin * W * H)); }
+        float s = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int ny = yy + pad - ky;
+            if (ny < 0 || ny % stride) continue;
+            const int oy = ny / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int nx = xx + pad - kx;
+                if (nx < 0 || nx % stride) continue;
+                const int ox = nx / stride;
+                if (ox >= Wo) continue;
+                s += load1(dcols + ((size_t)(b * Ho + oy) * Wo + ox) * ldc + (ky * k + kx) * Cin + c);
+            }
+        }
+        float* o = nchw ? dx + t : dx + ((size_t)(b * H + yy) * W + xx) * ld_dx + c;
+        *o = accumulate ? *o + s : s;
+    }
+}
+
+int grid1d(long long n) {
+    long long g = (n + 1023) / 1024;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+}  // namespace uf
+
+static int rows_sum_parts(int M) { return M < 128 ? M : 128; }
+extern "C" size_t uf_rows_sum_workspace_bytes(int M, int N) { return M <= 0 || N <= 0 ? 0 : (size_t)rows_sum_parts(M) * N * sizeof(float); }
+extern "C" int uf_rows_sum(const void* X, int ld, float* out, int M, int N, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(X && out && ws, UF_ERR_NULL, "uf_rows_sum: null pointer");
+    const int V = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(M > 0 && N > 0 && N % V == 0 && ld >= N && ld % V == 0 && ((uintptr_t)X % 16) == 0, UF_ERR_SHAPE, "uf_rows_sum: M=%d N=%d ld=%d (N, ld multiples of %d)", M, N, ld, V);
+    UF_REQUIRE(ws_bytes >= uf_rows_sum_workspace_bytes(M, N), UF_ERR_WORKSPACE, "uf_rows_sum: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = rows_sum_parts(M);
+    const dim3 grid((N / V + 255) / 256, P);
+    if (dtype == UF_BF16) hipLaunchKernelGGL(rows_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, (float*)ws, M, N, P);
+    else hipLaunchKernelGGL(rows_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, (float*)ws, M, N, P);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((N + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)ws, P, (size_t)N, out, N);
+    return check_launch("rows_sum");
+}
+
+extern "C" int uf_rpb_table_grad(const float* dbias_dense, float* dtable, int heads, void* stream) {
+    UF_REQUIRE(dbias_dense && dtable && heads > 0, UF_ERR_NULL, "uf_rpb_table_grad: null pointer / heads");
+    hipLaunchKernelGGL(rpb_table_grad_kernel, dim3((225 * heads + 255) / 256), dim3(256), 0, (hipStream_t)stream, dbias_dense, dtable, heads);
+    return check_launch("rpb_table_grad");
+}
+
+extern "C" int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, int H, int W, int Cin, int k, int stride, int pad, int nchw, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && cols, UF_ERR_NULL, "uf_im2col: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && k > 0 && stride > 0 && pad >= 0 && ldc >= k * k * Cin && (nchw || ld_x >= Cin), UF_ERR_SHAPE, "uf_im2col: shape");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long long total = (long long)B * Ho * Wo * ldc;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UF_BF16) hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (bf16*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw);
+    else hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (float*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw);
+    return check_launch("im2col");
+}
+
+extern "C" int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B, int H, int W, int Cin, int k, int stride, int pad, int nchw, int accumulate,
+                         uf_dtype dtype, void* stream) {
+    UF_REQUIRE(dcols && dx, UF_ERR_NULL, "uf_col2im: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && k > 0 && stride > 0 && pad >= 0 && ldc >= k * k * Cin && (nchw || ld_dx >= Cin), UF_ERR_SHAPE, "uf_col2im: shape");
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    const long long total = (long long)B * H * W * Cin;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UF_BF16) hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(grid1d(total)), dim3(256), 0, st, (const bf16*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate);
+    else hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate);
+    return check_launch("col2im");
 }

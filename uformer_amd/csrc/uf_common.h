@@ -185,12 +185,12 @@ __device__ __forceinline__ int window_row_to_token(int m, int H, int W, int shif
 // that walks a window calls window_geom once (its argument is wave-uniform -> the divisions run on the scalar unit) and
 // token() per row (two adds, two wrap-arounds, one multiply-add).  window_row_to_token above costs three integer divisions
 // per call (~100 VALU instructions), which the per-row callers paid 16 times per thread in front of their loads.
-struct WinGeom { int base, h0, w0, H, W; };
+struct WinGeom { int base, h0, w0, H, W, img; };
 __device__ __forceinline__ WinGeom window_geom(int bw, int H, int W, int shift) {
     const int nWc = W >> 3, nW = (H >> 3) * nWc;
     const int b = bw / nW, wi = bw - b * nW;
     const int wr = wi / nWc, wc = wi - wr * nWc;
-    return WinGeom{b * H * W, (wr << 3) + shift, (wc << 3) + shift, H, W};
+    return WinGeom{b * H * W, (wr << 3) + shift, (wc << 3) + shift, H, W, b};
 }
 __device__ __forceinline__ int window_token(const WinGeom& g, int t) {   // t = row within the window, 0..63
     int h = g.h0 + (t >> 3); if (h >= g.H) h -= g.H;

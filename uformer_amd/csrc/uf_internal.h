@@ -35,6 +35,11 @@ int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStre
 void debug_set_tbuf(void* p);
 bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads);
 // h1_out != NULL (and dtype bf16): the kernel also writes h1 = GELU(linear1(LN2(x_new))), T[B*H*W][4C]
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st);
+// drop: per-image DropPath scale of the attention branch (training forward) or NULL
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st,
+                      const float* drop = nullptr);
+// second half of LeFF with an optional per-image DropPath scale of the branch (uf_leff2.hip)
+int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2, float* x, int ld, int B, int H, int W, int C,
+                 uf_dtype dtype, const float* drop, hipStream_t st);
 
 }  // namespace uf

@@ -23,6 +23,7 @@ struct Leff2Params {
     const float* w9; const float* bdw;  // f32 [9][4C], [4C]
     const void* W2; const float* b2;    // T [C][4C], f32 [C]
     float* x; int ld;               // residual stream rows, in place
+    const float* drop;              // training: per-image DropPath scale of the branch (model.py:987) or NULL
     int B, H, W;
     unsigned long long* tbuf;   // optional per-role cycle totals of sampled blocks (uf_debug_set_tbuf)
 };
@@ -293,6 +294,7 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
     }
 
     // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
+    const float dscale = p.drop ? p.drop[b] : 1.0f;
 #pragma unroll
     for (int i = 0; i < TNW; ++i) {
         const int n = (wn * TNW + i) * 16 + fg * 4;
@@ -302,7 +304,7 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
             const int pm = (wm * TMW + j) * 16 + fr;
             const int ty = pm >> 3, tx = pm & 7;
             float* xp = p.x + ((size_t)(b * p.H + y0 + ty) * p.W + x0 + tx) * p.ld + n;
-            *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2);
+            *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2) * dscale;
         }
     }
     if (cw == 0 && lane == 0) {   // census entry written by the first consumer thread (thread 0 is a producer and has returned)
@@ -370,26 +372,34 @@ int launch_t(const Leff2Params& p, int C, hipStream_t st) {
 }
 
 }  // namespace
+unsigned long long* debug_get_tbuf();
 }  // namespace uf
 
-namespace uf { unsigned long long* debug_get_tbuf(); }
 using namespace uf;
 
-extern "C" int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2,
-                                     float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* stream) {
+namespace uf {
+int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2, float* x, int ld, int B, int H, int W, int C,
+                 uf_dtype dtype, const float* drop, hipStream_t st) {
     UF_REQUIRE(h1 && w9 && bdw && W2 && b2 && x, UF_ERR_NULL, "uf_dwconv_linear2_fwd: null pointer");
     UF_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: B=%d H=%d W=%d (multiples of 8)", B, H, W);
     UF_REQUIRE(ld >= C && ld % 4 == 0, UF_ERR_ALIGN, "uf_dwconv_linear2_fwd: ld=%d", ld);
     UF_REQUIRE(((uintptr_t)h1 % 16) == 0 && ((uintptr_t)W2 % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w9 % 16) == 0 &&
                    ((uintptr_t)bdw % 16) == 0 && ((uintptr_t)b2 % 16) == 0,
                UF_ERR_ALIGN, "uf_dwconv_linear2_fwd: operands must be 16-byte aligned");
-    UF_REQUIRE((long long)B * H * W * 4LL * C < 0x7fffffffLL, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: tensor too large for 32-bit indexing");
+    UF_REQUIRE((long long)H * W * 4LL * C * (long long)dtype_size(dtype) < 0xffffff00LL, UF_ERR_SHAPE,
+               "uf_dwconv_linear2_fwd: one image of the hidden tensor must stay under 4 GiB (32-bit buffer offsets)");
+    UF_REQUIRE((long long)B * H * W < 0x7fffffffLL / 4, UF_ERR_SHAPE, "uf_dwconv_linear2_fwd: too many tokens");
     Leff2Params p{};
-    p.tbuf = uf::debug_get_tbuf();
-    p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W;
-    hipStream_t st = (hipStream_t)stream;
+    p.tbuf = debug_get_tbuf();
+    p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W; p.drop = drop;
     if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
     if (dtype == UF_F32) return launch_t<float>(p, C, st);
     set_error("uf_dwconv_linear2_fwd: dtype %d", (int)dtype);
     return UF_ERR_UNSUPPORTED;
+}
+}  // namespace uf
+
+extern "C" int uf_dwconv_linear2_fwd(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2,
+                                     float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* stream) {
+    return uf::launch_leff2(h1, w9, bdw, W2, b2, x, ld, B, H, W, C, dtype, nullptr, (hipStream_t)stream);
 }

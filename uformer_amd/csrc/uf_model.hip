@@ -52,7 +52,7 @@ int check_block_args(const uf_block_params* p, const float* x, int ld, int B, in
 
 // fc1_done (optional): set when the fused kernel also produced the LeFF hidden h1 in w.h1 (whole-block calls only)
 int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask,
-              uf_dtype dtype, const BlockWs& w, hipStream_t st, bool* fc1_done = nullptr) {
+              uf_dtype dtype, const BlockWs& w, hipStream_t st, bool* fc1_done = nullptr, const float* drop = nullptr) {
     const int M = B * H * W;
     const size_t sz = dtype_size(dtype);
     const int heads = p->heads, hd = C / heads;
@@ -63,8 +63,9 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) {
         const bool with_fc1 = fc1_done && !no_fc1 && dtype == UF_BF16 && C >= 32;
         if (fc1_done) *fc1_done = with_fc1;
-        return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st);
+        return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st, drop);
     }
+    UF_REQUIRE(!drop, UF_ERR_UNSUPPORTED, "DropPath scales need the fused attention kernel (bf16, or f32 with C <= 256; no caller mask)");
     // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
     // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
@@ -85,7 +86,7 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 }
 
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
-              hipStream_t st, bool fc1_done = false) {
+              hipStream_t st, bool fc1_done = false, const float* drop = nullptr) {
     const int M = B * H * W;
     // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671) unless the attention kernel did it
     if (!fc1_done) {
@@ -94,7 +95,7 @@ int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     }
     // depthwise 3x3 + GELU over the whole H x W map, linear2, + residual: one kernel, the conv output
     // stays on chip                                      (model.py:659-661, :674-682, :987)
-    return uf_dwconv_linear2_fwd(w.h1, p->wdw9, p->bdw, p->w2_fm, p->b2, x, ld, B, H, W, C, dtype, st);
+    return launch_leff2(w.h1, p->wdw9, p->bdw, p->w2_fm, p->b2, x, ld, B, H, W, C, dtype, drop, st);
 }
 
 }  // namespace
@@ -138,6 +139,19 @@ extern "C" int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, in
     rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream, &fc1_done);
     if (rc) return rc;
     return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream, fc1_done);
+}
+
+extern "C" int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* drop_attn,
+                                        const float* drop_leff, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    int rc = check_block_args(p, x, ld, B, H, W, C, dtype);
+    if (rc) return rc;
+    BlockWs w;
+    rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
+    if (rc) return rc;
+    bool fc1_done = false;
+    rc = attn_half(p, x, ld, B, H, W, C, nullptr, 0, dtype, w, (hipStream_t)stream, &fc1_done, drop_attn);
+    if (rc) return rc;
+    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream, fc1_done, drop_leff);
 }
 
 extern "C" int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B,

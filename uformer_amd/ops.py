@@ -540,3 +540,80 @@ def mixup(x: Tensor, lam: Tensor, perm: Tensor) -> Tensor:
         _lib.check(_lib.load().uf_mixup(_ptr(x), _ptr(out), _ptr(_c(lam.reshape(-1), torch.float32)), _ptr(_c(perm, torch.int32)), B,
                                         x.numel() // B, _stream()), "uf_mixup")
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# a15: reductions / patch gathers of the backward, fused training forward of a block
+# ---------------------------------------------------------------------------------------
+def rows_sum(x: Tensor) -> Tensor:
+    """f32 (N,) = sum over the rows of x (M, N) (bf16 / f32), fixed order (modulator gradient: x = d(xn) as (n_windows, 64*C))."""
+    _dev(x)
+    dt = uf_dtype(x.dtype)
+    x = _c(x)
+    M, N = x.shape
+    out = torch.empty(N, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_rows_sum_workspace_bytes(M, N)
+    ws = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_rows_sum(_ptr(x), N, _ptr(out), M, N, dt, _ptr(ws), nbytes, _stream()), "uf_rows_sum")
+    return out
+
+
+def rpb_table_grad(dbias: Tensor) -> Tensor:
+    """(heads,64,64) dense bias gradient -> (225, heads) relative_position_bias_table gradient (model.py:500-502 transposed)."""
+    _dev(dbias)
+    dbias = _c(dbias, torch.float32)
+    heads = dbias.shape[0]
+    out = torch.empty(225, heads, dtype=torch.float32, device=dbias.device)
+    with torch.cuda.device(dbias.device):
+        _lib.check(_lib.load().uf_rpb_table_grad(_ptr(dbias), _ptr(out), heads, _stream()), "uf_rpb_table_grad")
+    return out
+
+
+def im2col(x: Tensor, B: int, H: int, W: int, Cin: int, k: int, stride: int, pad: int, dtype, nchw: bool = False) -> Tensor:
+    """Patch matrix (B*Ho*Wo, ldc) of a conv input: f32 token rows (B*H*W, Cin) or an NCHW image; column (ky*k+kx)*Cin + c,
+    ldc = k*k*Cin rounded up to 8 (zero columns)."""
+    _dev(x)
+    x = _c(x, torch.float32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    ldc = (k * k * Cin + 7) // 8 * 8
+    dt = uf_dtype(dtype)
+    cols = torch.empty((B * Ho * Wo, ldc), dtype=torch_dtype(dt), device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_im2col(_ptr(x), Cin, _ptr(cols), ldc, B, H, W, Cin, k, stride, pad, int(nchw), dt, _stream()), "uf_im2col")
+    return cols
+
+
+def col2im(dcols: Tensor, B: int, H: int, W: int, Cin: int, k: int, stride: int, pad: int, nchw: bool = False, out: Optional[Tensor] = None) -> Tensor:
+    """Transpose of im2col: f32 (B*H*W, Cin) rows (or NCHW) = gathered sum of the matching dcols entries; ``out`` given: added to it."""
+    _dev(dcols, out)
+    dt = uf_dtype(dcols.dtype)
+    dcols = _c(dcols)
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, Cin, H, W) if nchw else (B * H * W, Cin), dtype=torch.float32, device=dcols.device)
+    elif not out.is_contiguous() or out.dtype != torch.float32:
+        raise UformerHipError("col2im: out must be contiguous float32")
+    with torch.cuda.device(dcols.device):
+        _lib.check(_lib.load().uf_col2im(_ptr(dcols), dcols.shape[1], _ptr(out), Cin, B, H, W, Cin, k, stride, pad, int(nchw), int(acc), dt, _stream()),
+                   "uf_col2im")
+    return out
+
+
+def lewin_block_train_fwd(bp, x: Tensor, B: int, H: int, W: int, dtype, drop_attn: Optional[Tensor] = None, drop_leff: Optional[Tensor] = None) -> Tensor:
+    """Training forward of one LeWin block on the two fused inference kernels with DropPath scales (f32 (B,) per branch or None):
+    returns the new stream; ``x`` (f32 (B*H*W, C)) is left untouched -- it is what the backward keeps."""
+    _dev(x, drop_attn, drop_leff)
+    dt = uf_dtype(dtype)
+    y = _c(x, torch.float32).clone()
+    Cc = y.shape[-1]
+    lib = _lib.load()
+    nbytes = lib.uf_block_workspace_bytes(B * H * W, Cc, dt)
+    ws = _ws(nbytes, y.device)
+    da = None if drop_attn is None else _c(drop_attn, torch.float32)
+    dl = None if drop_leff is None else _c(drop_leff, torch.float32)
+    with torch.cuda.device(y.device):
+        _lib.check(lib.uf_lewin_block_train_fwd(bp, _ptr(y), Cc, B, H, W, Cc, _ptr(da), _ptr(dl), dt, _ptr(ws), nbytes, _stream()),
+                   "uf_lewin_block_train_fwd")
+    return y
