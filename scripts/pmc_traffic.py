@@ -3,7 +3,7 @@
 (scripts/pmc_passes.sh -> <dir>/pmcC_pmc.csv, <dir>/pmcD_pmc.csv), keyed by the library's timing symbol so
 bench.py can attach it to `roofline.traffic`.
 
-    python scripts/pmc_traffic.py gpurun_out profiles/r01_pmc_traffic.json
+    python scripts/pmc_traffic.py gpurun_out profiles/r02_pmc_traffic.json
 
 Corrections (MI355X_MICROARCH.md, HBM section): rocprofv3 reports both counters in KiB; on gfx950 FETCH_SIZE counts
 128-B requests of wide (16 B/lane) streaming reads as 64 B, so it is DOUBLED here -- every hot read in these kernels
@@ -21,9 +21,9 @@ def symbol(kernel):
     m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)>", kernel)
     if m:
         return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
-    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+)>", kernel)
+    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)      # <T, C, NPG, NC, NBUF, WPS>
     if m:
-        return f"leff2_bf16_c{m.group(1)}_np{m.group(2)}_nc{m.group(3)}"
+        return f"leff2_bf16_c{m.group(1)}_np{4 * int(m.group(2))}_nc{m.group(3)}"
     m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)>", kernel)
     if m:
         return f"gemm_bf16_bn{m.group(1)}_a{m.group(2)}_e{m.group(3)}"
@@ -51,13 +51,15 @@ def first(*names):
         if os.path.exists(f"{src}/{n}"):
             return f"{src}/{n}"
     raise SystemExit(f"none of {names} under {src}")
-fetch, write = load(first("pmcC_pmc.csv", "r01_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r01_final_pmcD.csv"), "WRITE_SIZE")
+fetch, write = load(first("pmcC_pmc.csv", "r02_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r02_final_pmcD.csv"), "WRITE_SIZE")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before it quotes these numbers)
 out = {}
 for s in sorted(fetch):
     f, n = fetch[s]
     w = write.get(s, (0.0, 0))[0]
     out[s] = {"fetch_bytes_per_launch": 2.0 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2.0 * f + w, "dispatches_profiled": n}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1; "
+json.dump({"kernel_source_sha": bench.kernel_source_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-mode (UF_STREAMS=1); "
                      "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; average over the launches of a symbol",
            "kernels": out}, open(dst, "w"), indent=1)
 for s, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

@@ -110,3 +110,70 @@ def test_two_rank_gradient_allreduce_matches_single_process():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-4 and err3 < 1e-5 and nb > 3
+
+
+def _overlap_worker(rank, world, port, q):
+    """OverlappedGradientAllReduce driven the way UformerTape.backward drives it: gradients arrive stage by stage in reverse-sweep
+    order (head, decoder 3..0, bottleneck, encoder 3..0, stem), every bucket is reduced the moment its last gradient is in, p.grad
+    is a view of the bucket, and the average is folded into the optimizer's grad_scale."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import uformer_oracle as O
+    from uformer_amd import dist as ud
+    from uformer_amd import spec
+    torch.set_num_threads(2)
+    ud.init_process_group("gloo")
+    cfg = spec.arch_config("tiny", 128)
+    kw = dict(img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
+    gb = 2
+    x, tgt = spec.synth_input(gb, 128, 128, 6), spec.synth_input(gb, 128, 128, 7)
+
+    def grads_of(xs, ts, weight):
+        sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 5).items()}
+        (O.charbonnier_loss(O.uformer_forward(xs, sd, **kw), ts) * weight).backward()
+        return {k: v for k, v in sd.items() if v.is_floating_point()}
+
+    a, b = ud.shard_batch(gb, rank, world)
+    mine = grads_of(x[a:b], tgt[a:b], world * (b - a) / gb)
+    params = {k: torch.nn.Parameter(v.detach().clone()) for k, v in mine.items()}
+    sink = ud.OverlappedGradientAllReduce(list(params.items()), bucket_bytes=256 << 10)
+    assert all(p.grad is not None and p.grad.data_ptr() == sink.views[k].data_ptr() for k, p in params.items())
+    stages = ["output_proj", "decoderlayer_3", "upsample_3", "decoderlayer_2", "upsample_2", "decoderlayer_1", "upsample_1", "decoderlayer_0", "upsample_0",
+              "conv", "dowsample_3", "encoderlayer_3", "dowsample_2", "encoderlayer_2", "dowsample_1", "encoderlayer_1", "dowsample_0", "encoderlayer_0",
+              "input_proj"]
+    dropped = "encoderlayer_2.blocks.0.mlp.linear1.0.weight"
+    sink.begin_step()
+    launched_at = []
+    for st in stages:
+        group = {k: (None if (k == dropped and rank == 1) else v.grad) for k, v in mine.items() if k.split(".")[0] == st}
+        assert group, st
+        sink.deliver(group)
+        launched_at.append(len(sink.launch_order))
+    sink.finish()
+    assert sorted(sink.launch_order) == list(range(len(sink.buckets)))
+    assert launched_at[len(stages) // 2] >= 1 and launched_at[len(stages) // 2] < len(sink.buckets)     # collectives start mid-sweep
+    if rank == 0:
+        ref = grads_of(x, tgt, 1.0)
+        err = 0.0
+        for k, p in params.items():
+            got = p.grad * sink.grad_scale
+            want = ref[k].grad if k != dropped else mine[k].grad / world
+            err = max(err, float((got - want).abs().max() / want.abs().max()))
+        q.put((err, len(sink.buckets), list(sink.launch_order)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_allreduce_delivers_in_sweep_order():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, nb, order = q.get(timeout=400)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-4 and nb > 3
+    assert order[0] == 0        # the bucket holding the decoder's last blocks (first to finish in the reverse sweep) goes first

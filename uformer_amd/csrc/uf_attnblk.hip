@@ -47,6 +47,9 @@ struct AttnBlkParams {
 constexpr float LOG2E = 1.4426950408889634f;
 
 // weight-fragment ring depths (k-steps of L2 -> register loads in flight) of the three GEMM phases at C >= 256
+#ifndef UF_ABL
+#define UF_ABL 0   // phase-0 ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads); 0 in every shipped build
+#endif
 #ifndef UF_LN_ROTATE
 #define UF_LN_ROTATE 0
 #endif
@@ -219,12 +222,36 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         const int rot = UF_LN_ROTATE ? bw : 0;
 #pragma unroll 1
         for (int r0 = 0; r0 < 64; r0 += RPP * U) {
-            f32x4 v[U][V4];
+            f32x4 v[U][V4], md[U][V4];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int src = window_token(geo, r0 + ((u + rot) & (U - 1)) * RPP + tid / LPR);
 #pragma unroll
-                for (int i = 0; i < V4; ++i) v[u][i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4);
+                for (int i = 0; i < V4; ++i) {
+                    if (UF_ABL == 1) v[u][i] = f32x4{(float)src, (float)i, (float)sub, 1.0f};   // ablation: no x loads
+                    else v[u][i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4);
+                }
+            }
+            // the modulator rows of the same tokens, requested together with x: read inside the normalisation loop they were
+            // 16 dependent L2 round trips per thread (ablation: 11 K of the 23 K cycles of this phase at C = 256, 14 K at C = 512)
+            if (p.modulator && UF_ABL != 3) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int row = r0 + ((u + rot) & (U - 1)) * RPP + tid / LPR;
+#pragma unroll
+                    for (int i = 0; i < V4; ++i) md[u][i] = *reinterpret_cast<const f32x4*>(p.modulator + (size_t)row * C + (i * LPR + sub) * 4);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int i = 0; i < V4; ++i) md[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            f32x4 gm[V4], bt[V4];
+#pragma unroll
+            for (int i = 0; i < V4; ++i) {
+                gm[i] = *reinterpret_cast<const f32x4*>(p.gamma + (i * LPR + sub) * 4);
+                bt[i] = *reinterpret_cast<const f32x4*>(p.beta + (i * LPR + sub) * 4);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -247,8 +274,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {
                     const int c = (i * LPR + sub) * 4;
-                    f32x4 y = v[u][i] * rstd * *reinterpret_cast<const f32x4*>(p.gamma + c) + *reinterpret_cast<const f32x4*>(p.beta + c);
-                    if (p.modulator) y += *reinterpret_cast<const f32x4*>(p.modulator + (size_t)row * C + c);  // model.py:966-969
+                    f32x4 y = v[u][i] * rstd * gm[i] + bt[i] + md[u][i];      // + modulator (model.py:966-969), zeros in the encoder
+                    if (UF_ABL == 2) y = v[u][i];                             // ablation: no LN math
                     store4(reinterpret_cast<T*>(Xn + row * SA) + c, y);
                 }
             }

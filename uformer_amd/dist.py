@@ -139,3 +139,103 @@ class GradientAllReduce:
                 else:
                     p.grad.copy_(g)
                 off += n
+
+
+class OverlappedGradientAllReduce:
+    """The gradient exchange overlapped with the reverse sweep.
+
+    * ``param.grad`` of every parameter IS a view into a flat f32 bucket (about ``bucket_bytes`` each, parameters in reverse
+      registration order = the order the reverse sweep finishes them): nothing is packed or unpacked around the collective.
+    * the training tape (uformer_amd/train.py ``UformerTape.backward``) calls ``deliver`` with the gradients of every stage as soon
+      as the sweep has finished it; they are written into their bucket views, and a bucket whose last gradient has arrived is
+      all-reduced at once with ``async_op=True`` -- RCCL runs it on its own stream behind the producing kernels, while the compute
+      stream goes on with the next stage's backward.
+    * the sum is NOT divided: ``grad_scale`` (1 / world) is handed to ``uformer_amd.optim.AdamW.step`` which folds it into the
+      update (``uf_adamw_step``), so the averaged gradient never makes an extra pass through HBM.
+    Use: ``sink = OverlappedGradientAllReduce(model); model.grad_sink = sink`` then per step
+    ``sink.begin_step(); loss.backward(); sink.finish(); opt.step(grad_scale=sink.grad_scale)``."""
+
+    def __init__(self, model_or_named_params, bucket_bytes: int = 25 << 20):
+        named = list(model_or_named_params.named_parameters()) if hasattr(model_or_named_params, "named_parameters") else list(model_or_named_params)
+        named = [(n, p) for n, p in named if p.requires_grad][::-1]
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        self.bucket_of, self.buckets = {}, []
+        cur, size = [], 0
+        for i, p in enumerate(self.params):
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(i)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.views = [], {}
+        for b, idxs in enumerate(self.buckets):
+            dev = self.params[idxs[0]].device
+            flat = torch.zeros(sum(self.params[i].numel() for i in idxs), dtype=torch.float32, device=dev)
+            self.flat.append(flat)
+            off = 0
+            for i in idxs:
+                p = self.params[i]
+                v = flat[off:off + p.numel()].view_as(p)
+                self.views[self.names[i]] = v
+                self.bucket_of[self.names[i]] = b
+                p.grad = v                                         # the optimizer reads the bucket directly
+                off += p.numel()
+        self.launch_order = []                                     # bucket indices in the order their collectives were issued (tests)
+        self.begin_step()
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def begin_step(self) -> None:
+        self._missing = [len(b) for b in self.buckets]
+        self._seen = set()
+        self._works = []
+        self.launch_order = []
+
+    def _launch(self, b: int) -> None:
+        self.launch_order.append(b)
+        if self.world > 1:
+            self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def deliver(self, grads) -> None:
+        """grads: {parameter name: gradient tensor or None}.  None (a branch DropPath removed on this rank) counts as zeros: the
+        collective must be the same on all ranks."""
+        for name, g in grads.items():
+            if name not in self.views or name in self._seen:
+                continue
+            self._seen.add(name)
+            v = self.views[name]
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g.reshape(v.shape))
+            b = self.bucket_of[name]
+            self._missing[b] -= 1
+            if self._missing[b] == 0:
+                self._launch(b)
+
+    def finish(self) -> None:
+        """Buckets that never completed (parameters without a gradient this step) are zero-filled for the missing entries and
+        reduced now; then the compute stream is made to wait for every collective."""
+        for b, idxs in enumerate(self.buckets):
+            if self._missing[b] > 0:
+                for i in idxs:
+                    if self.names[i] not in self._seen:
+                        self.views[self.names[i]].zero_()
+                self._missing[b] = 0
+                self._launch(b)
+        for w in self._works:
+            w.wait()
+        self._works = []
+        for i, p in enumerate(self.params):                        # autograd may have replaced .grad: point it back at the bucket
+            if p.grad is None or p.grad.data_ptr() != self.views[self.names[i]].data_ptr():
+                p.grad = self.views[self.names[i]]

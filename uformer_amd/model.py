@@ -526,6 +526,10 @@ class Uformer(nn.Module):
                                       "(Uformer_T, head_dim 16) runs inference only -- use torch.no_grad()")
         sd = self.state_dict(keep_vars=True)
         names, params = list(sd.keys()), list(sd.values())
+        sink = getattr(self, "grad_sink", None)
+        if sink is not None:        # gradients go straight into the all-reduce buckets as the reverse sweep finishes each stage
+            names = train.NamesWithSink(names)
+            names.sink = sink
         rates = self.drop_path_rates() if self.training else []      # eval(): DropPath is the identity (timm)
         drop = getattr(self, "_drop_scales_override", None) if self.training else None
         if drop is None and any(r > 0 for r in rates):

@@ -195,7 +195,7 @@ class UformerTape:
                  recompute: Optional[bool] = None, on_stage_done=None):
         self.sd, self.cfg, self.T, self.drop = sd, cfg, dtype, drop_scales
         self.recompute = (dtype == torch.bfloat16) if recompute is None else recompute
-        self.on_stage_done = on_stage_done          # callback(list of parameter names whose gradients are final), reverse sweep order
+        self.on_stage_done = on_stage_done          # callback({name: gradient}) for every group of parameters whose gradients are final, in reverse-sweep order
 
     def forward(self, img: Tensor) -> Tensor:
         from .spec import STAGES
@@ -247,10 +247,11 @@ class UformerTape:
     def backward(self, dy: Tensor) -> Tuple[Tensor, Grads]:
         from .spec import STAGES
         sd, cfg, T, B, H, res = self.sd, self.cfg, self.T, self.B, self.H, self.res
+        g: Grads = {}
 
         def done(names):
             if self.on_stage_done is not None:
-                self.on_stage_done(list(names))
+                self.on_stage_done({n: g[n] for n in names})
 
         def stage_bwd(s: int, d: Tensor, g: Grads) -> Tensor:
             C = d.shape[1]
@@ -269,7 +270,6 @@ class UformerTape:
             done(names)
             return d.reshape(-1, C)
 
-        g: Grads = {}
         dy = dy.float()
         dy_rows = dy.permute(0, 2, 3, 1).reshape(B * H * H, 3)
         C8 = self.head_in.shape[1]
@@ -327,10 +327,11 @@ class UformerFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, img, cfg, dtype, drop_scales, names, *params):
+        sink = names.sink if isinstance(names, NamesWithSink) else None
         sd = {n: p.detach() for n, p in zip(names, params)}
-        tape = UformerTape(sd, cfg, dtype, drop_scales)
+        tape = UformerTape(sd, cfg, dtype, drop_scales, on_stage_done=None if sink is None else sink.deliver)
         y = tape.forward(img.detach().float().contiguous())
-        ctx.tape, ctx.names = tape, names
+        ctx.tape, ctx.names, ctx.sink = tape, names, sink
         ctx.img_needs_grad = img.requires_grad
         return y
 
@@ -338,8 +339,16 @@ class UformerFunction(torch.autograd.Function):
     def backward(ctx, dy):
         dimg, g = ctx.tape.backward(dy.contiguous())
         ctx.tape = None                                                           # free the saved activations
-        grads = tuple(g.get(n) for n in ctx.names)
+        if ctx.sink is not None:      # the gradients already sit in the sink's buckets (= param.grad) and are being all-reduced
+            grads = tuple(None for _ in ctx.names)
+        else:
+            grads = tuple(g.get(n) for n in ctx.names)
         return (dimg if ctx.img_needs_grad else None, None, None, None, None) + grads
+
+
+class NamesWithSink(list):
+    """parameter names + the gradient sink (uformer_amd.dist.OverlappedGradientAllReduce) the tape delivers to during backward"""
+    sink = None
 
 
 def sample_drop_scales(rates: Sequence[float], B: int, device, generator: Optional[torch.Generator] = None) -> Tensor:
