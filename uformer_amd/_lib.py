@@ -120,7 +120,10 @@ def load():
                 f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the hot path.")
         lib = C.CDLL(LIB_PATH)
+        older = os.environ.get("UF_ALLOW_OLDER_LIB") == "1"   # A/B against a library of an earlier round (scripts/official_run.sh): skip what it lacks
         for name, (res, args) in SIGNATURES.items():
+            if older and not hasattr(lib, name):
+                continue
             fn = getattr(lib, name)  # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args

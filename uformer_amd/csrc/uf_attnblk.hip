@@ -47,6 +47,20 @@ struct AttnBlkParams {
 constexpr float LOG2E = 1.4426950408889634f;
 
 // weight-fragment ring depths (k-steps of L2 -> register loads in flight) of the three GEMM phases at C >= 256
+#ifndef UF_P1_OFFSET
+#define UF_P1_OFFSET 0
+#endif
+#ifndef UF_FC1_OFFSET
+#define UF_FC1_OFFSET 0
+#endif
+#ifndef UF_STAGGER
+#define UF_STAGGER 0
+#endif
+#ifndef UF_SETPRIO
+#define UF_SETPRIO 0
+#endif
+#define UF_PRIO_UP() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define UF_PRIO_DN() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef UF_ABL
 #define UF_ABL 0   // phase-0 ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads); 0 in every shipped build
 #endif
@@ -114,6 +128,7 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
 #pragma unroll
     for (int j = 0; j < 4; ++j) rowoff[j] = (size_t)window_token(geo, j * 16 + fr) * N4;
     if (wave < UNITS) unit_prefetch(wave);
+    if (WAVES == 8 && UF_FC1_OFFSET > 0 && wave >= 4) __builtin_amdgcn_s_sleep(UF_FC1_OFFSET * (C / 256) > 127 ? 127 : UF_FC1_OFFSET * (C / 256));   // as in phase 1
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
         const int nbase = u * 64;
@@ -137,10 +152,12 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
             if (ks + RING - 1 < KS) wload(ks + RING - 1, (ks + RING - 1) % RING);
             if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
+            UF_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], wf[ks % RING][i], af[ks & 1][j]);   // weight as A: lane = 4 channels of one token
+            UF_PRIO_DN();
             __builtin_amdgcn_sched_barrier(0);
         }
         if (u + WAVES < UNITS) unit_prefetch(u + WAVES);
@@ -189,6 +206,10 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     };
     stamp(0);
     Census census; census.begin();
+    if (UF_STAGGER > 0 && ((blockIdx.x >> 8) & 1)) {      // experiment: offset the second resident workgroup of a CU by UF_STAGGER x 8 K cycles
+#pragma unroll
+        for (int k = 0; k < UF_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+    }
 
     // The small tables of the later phases (relative-position bias, q/k/v and proj biases) are REQUESTED here, all at once and
     // unconditionally (clamped index), and stored to LDS after phase 0.  They used to be copied by a load -> store loop behind
@@ -299,6 +320,10 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
 
     // ---------------- phase 1: per-unit QKV projection + attention, all in registers -------------------
+    // 8-wave workgroups put TWO of their waves on every SIMD, and the barriers keep them in lockstep: both fight for the matrix
+    // pipe during the projections, then both leave it idle during the softmax.  Holding back the second half of the waves by about
+    // one projection lets a SIMD run one wave's MFMAs beside the other's VALU work (UF_P1_OFFSET x 64 cycles, 0 = off).
+    if (WAVES == 8 && UF_P1_OFFSET > 0 && wave >= 4) __builtin_amdgcn_s_sleep(UF_P1_OFFSET * (C / 256) > 127 ? 127 : UF_P1_OFFSET * (C / 256));
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
         const int h = u / (4 / QT), q0 = (u % (4 / QT)) * QT;   // head, first query tile
@@ -342,6 +367,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
             if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             const int s = ks & 1, sw = ks % WR;
+            UF_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -354,6 +380,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(av[i][j], af[s][j], wf[sw][4 + i]);        // v: activation as A operand
             }
+            UF_PRIO_DN();
             __builtin_amdgcn_sched_barrier(0);
         }
         if (u == wave) stamp(3);
@@ -522,10 +549,12 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
             if (ks + PR - 1 < KS) wload(ks + PR - 1, (ks + PR - 1) % PR);
             if (ks + 1 < KS) aload(ks + 1, (ks + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
+            UF_PRIO_UP();
 #pragma unroll
             for (int i = 0; i < TNW; ++i)
 #pragma unroll
                 for (int j = 0; j < TMW; ++j) mma16(acc[i][j], wf[ks % PR][i], af[ks & 1][j]);
+            UF_PRIO_DN();
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(7);

@@ -358,6 +358,150 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const T* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient, second version: 128 x 128 output tile per workgroup (4 waves x 64 x 64), tokens in steps of 32.
+// dY[32][128] and X[32][128] go to LDS exactly as they sit in HBM (token-major rows, 16-byte pieces: coalesced loads, 16-byte LDS
+// stores, register-staged double buffer); the MFMA operands -- 8 consecutive TOKENS of one column per lane -- come out of LDS
+// through gfx950's transposing read ds_read_b64_tr_b16: within a 16-lane group, lane q addresses the 8-byte chunk
+// [row q>>2][4 columns (q&3)*4..] of a 4 x 16 block and receives column q of its 4 rows (mapping probed on the hardware:
+// scripts/ubench_hip/trread.hip).  Two reads give a lane its 8 tokens.  No transposing stores, 16 MFMAs per wave per step
+// instead of 4, and every dY / X byte is read by N/128 resp. K/128 workgroups instead of N/64, K/64.
+// LDS layout [32 rows][256 B] with the 8-byte chunk index XORed by 4 * ((row & 3) | ((row >> 3) & 1) << 2): the 8 rows x 4 chunks a
+// half-wave reads in one instruction land on 32 distinct bank pairs (conflict-free), and 16-byte stores stay contiguous.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned wg2_off(int row, int chunk) {     // byte offset of 8-byte chunk `chunk` (0..31) of token row `row`
+    const int rho = (row & 3) | (((row >> 3) & 1) << 2);
+    return (unsigned)(row * 256 + ((chunk ^ (rho << 2)) << 3));
+}
+
+__global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ X, int ldx,
+                                                               float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) char Ys[2][32 * 256];
+    __shared__ __attribute__((aligned(16))) char Xs[2][32 * 256];
+    __shared__ float Bs[16][128 + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k_tiles = (K + 127) / 128;
+    const int n0 = (blockIdx.x / k_tiles) * 128, k0 = (blockIdx.x % k_tiles) * 128;
+    const int wn = wave >> 1, wk = wave & 1;                 // 64 x 64 quadrant of this wave
+    const bool do_bias = (blockIdx.x % k_tiles) == 0;
+    const int steps_all = (M + 31) / 32;
+    const int s0 = (int)((long long)steps_all * blockIdx.y / gridDim.y), s1 = (int)((long long)steps_all * (blockIdx.y + 1) / gridDim.y);
+
+    // loader role: pieces pc = tid and tid + 256 of each [32][128] tile: row pc >> 4, 16-byte piece pc & 15 (same piece for both)
+    const int prow = tid >> 4, pseg = tid & 15;
+    const int cn = n0 + pseg * 8, ck = k0 + pseg * 8;
+    const bool okn = cn < N, okk = ck < K;                   // N, K are multiples of 8: a piece is entirely in or out
+    const bf16* ysrc = dY + (okn ? cn : 0);
+    const bf16* xsrc = X + (okk ? ck : 0);
+    u32x4 ry[2], rx[2];
+    auto fetch = [&](int s) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = s * 32 + prow + 16 * q;
+            const int mc = m < M ? m : M - 1;                // clamped, unconditional; masked below
+            ry[q] = *reinterpret_cast<const u32x4*>(ysrc + (size_t)mc * ldy);
+            rx[q] = *reinterpret_cast<const u32x4*>(xsrc + (size_t)mc * ldx);
+        }
+    };
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    auto stash = [&](int s, int buf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int row = prow + 16 * q;
+            const bool live = s * 32 + row < M;
+            const u32x4 zy = (live && okn) ? ry[q] : u32x4{0, 0, 0, 0}, zx = (live && okk) ? rx[q] : u32x4{0, 0, 0, 0};
+            *reinterpret_cast<u32x4*>(Ys[buf] + wg2_off(row, pseg * 2)) = zy;      // chunks 2*pseg, 2*pseg+1 stay adjacent under the XOR
+            *reinterpret_cast<u32x4*>(Xs[buf] + wg2_off(row, pseg * 2)) = zx;
+            if (do_bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(zy[e] << 16); bsum[2 * e + 1] += __uint_as_float(zy[e] & 0xffff0000u); }
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned ybase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&Ys[0][0];
+    const unsigned xbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&Xs[0][0];
+    // operand addressing: lane (group fg, q = fr) reads token rows 8*fg + (fr >> 2) [+4 = +1024 B for the second half: same XOR
+    // pattern], chunk (col0 / 4) + (fr & 3) of the 16-column tile i
+    const int trow = 8 * fg + (fr >> 2);
+    unsigned yaddr[4], xaddr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        yaddr[i] = ybase + wg2_off(trow, (wn * 64 + i * 16) / 4 + (fr & 3));
+        xaddr[i] = xbase + wg2_off(trow, (wk * 64 + i * 16) / 4 + (fr & 3));
+    }
+
+    if (s0 < s1) { fetch(s0); stash(s0, 0); }
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        if (s + 1 < s1) fetch(s + 1);                       // global loads of the next step fly under this step's MFMAs
+        // all 16 transposing reads of the step and their wait in ONE asm statement (early-clobber outputs): hipcc does not track
+        // asm loads, so nothing may touch the destinations before the s_waitcnt inside the string (cdna_hip_programming.md 5.7)
+        u32x2 y0[4], y1[4], x0[4], x1[4];
+        const unsigned bo = (unsigned)buf * 8192u;
+        const unsigned ya0 = yaddr[0] + bo, ya1 = yaddr[1] + bo, ya2 = yaddr[2] + bo, ya3 = yaddr[3] + bo;
+        const unsigned xa0 = xaddr[0] + bo, xa1 = xaddr[1] + bo, xa2 = xaddr[2] + bo, xa3 = xaddr[3] + bo;
+        asm volatile(
+            "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %20 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %10, %21\n\tds_read_b64_tr_b16 %11, %21 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %12, %22\n\tds_read_b64_tr_b16 %13, %22 offset:1024\n\t"
+            "ds_read_b64_tr_b16 %14, %23\n\tds_read_b64_tr_b16 %15, %23 offset:1024\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(y0[0]), "=&v"(y1[0]), "=&v"(y0[1]), "=&v"(y1[1]), "=&v"(y0[2]), "=&v"(y1[2]), "=&v"(y0[3]), "=&v"(y1[3]),
+              "=&v"(x0[0]), "=&v"(x1[0]), "=&v"(x0[1]), "=&v"(x1[1]), "=&v"(x0[2]), "=&v"(x1[2]), "=&v"(x0[3]), "=&v"(x1[3])
+            : "v"(ya0), "v"(ya1), "v"(ya2), "v"(ya3), "v"(xa0), "v"(xa1), "v"(xa2), "v"(xa3)
+            : "memory");
+        Frag<bf16> a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i].v = u32x4{y0[i][0], y0[i][1], y1[i][0], y1[i][1]};
+            b[i].v = u32x4{x0[i][0], x0[i][1], x1[i][0], x1[i][1]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mma16(acc[i][j], a[i], b[j]);
+        if (s + 1 < s1) stash(s + 1, buf ^ 1);              // the other buffer: last read in step s-1, all waves passed the barrier since
+        __syncthreads();
+    }
+    // ---- partial tile: D row = 4*fg + reg -> n, col = fr -> k
+    float* wp = ws_w + (size_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + fg * 4 + r, k = k0 + wk * 64 + j * 16 + fr;
+                if (n < N && k < K) wp[(size_t)n * K + k] = acc[i][j][r];
+            }
+    if (do_bias) {   // column sums of this chunk's dY slab: the 16 row-threads of a piece meet in LDS, fixed order
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Bs[prow][pseg * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += Bs[r][tid];
+            ws_b[(size_t)blockIdx.y * N + n0 + tid] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Window attention backward (WindowAttention.forward, model.py:494-519, without the projections):
 //   P = softmax(q k^T + bias + mask);   dV = P^T dO;   dP = dO V^T;   dS = P o (dP - rowsum(dP o P));
 //   dq = dS k;   dk = dS^T q;   dbias[h] = sum over windows of dS        (q is the SCALED query the forward stores)
@@ -631,8 +775,10 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     return check_launch("dwconv3x3_wgrad_finalize");
 }
 
-static int wgrad_chunks(int M, int N, int K) {
-    const int tiles = ((N + 63) / 64) * ((K + 63) / 64), steps = (M + 31) / 32;
+static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullptr; return !off; }   // UF_WGRAD_V1=1: first version (A/B, tests)
+static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
+    const int T = (dtype == UF_BF16 && wgrad_v2()) ? 128 : 64;
+    const int tiles = ((N + T - 1) / T) * ((K + T - 1) / T), steps = (M + 31) / 32;
     int S = 2048 / tiles;
     if (S > steps) S = steps;
     if (S > 256) S = 256;
@@ -641,7 +787,8 @@ static int wgrad_chunks(int M, int N, int K) {
 
 extern "C" size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return (size_t)wgrad_chunks(M, N, K) * ((size_t)N * K + N) * sizeof(float);
+    const int s1 = wgrad_chunks(M, N, K, UF_F32), s2 = wgrad_chunks(M, N, K, UF_BF16);     // the dtype is not an argument: size for either kernel
+    return (size_t)(s1 > s2 ? s1 : s2) * ((size_t)N * K + N) * sizeof(float);
 }
 
 extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
@@ -655,15 +802,18 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     const size_t need = uf_linear_wgrad_workspace_bytes(M, N, K);
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_linear_wgrad: workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const int S = wgrad_chunks(M, N, K);
+    const bool v2 = dtype == UF_BF16 && wgrad_v2();
+    const int S = wgrad_chunks(M, N, K, dtype);
     float* ws_w = (float*)ws;
     float* ws_b = ws_w + (size_t)S * N * K;
-    const dim3 grid(((N + 63) / 64) * ((K + 63) / 64), S);
+    const int TT = v2 ? 128 : 64;
+    const dim3 grid(((N + TT - 1) / TT) * ((K + TT - 1) / TT), S);
     char name[96] = "";
     if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype == UF_BF16 ? "bf16" : "f32", M, N, K);
     {
         ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
-        if (dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
+        if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
+        else if (dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
         else hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, ws_w, ws_b, M, N, K);
     }
     int rc = check_launch("linear_wgrad");
