@@ -129,6 +129,15 @@ int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, voi
 int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H,
                      int W, int C, int gelu, uf_dtype dtype, void* stream);
 
+/* training forms of the stencil (uformer_amd/train.py; model.py:657-660 and its backward):
+ *   uf_dwconv3x3_pre_gelu_fwd: pre_out = stencil + bias AND act_out = GELU(pre_out as stored), one pass (the backward needs both);
+ *   uf_dwconv3x3_mul_dgelu: out = stencil(dy; flipped taps, no bias) as stored * GELU'(pre): the gradient through the depthwise
+ *     conv AND the GELU in front of it (uf_dwconv3x3_fwd + uf_gelu_bwd in one pass). */
+int uf_dwconv3x3_pre_gelu_fwd(const void* x, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H,
+                              int W, int C, uf_dtype dtype, void* stream);
+int uf_dwconv3x3_mul_dgelu(const void* dy, const float* w9_flipped, const void* pre, void* out, int B, int H, int W, int C,
+                           uf_dtype dtype, void* stream);
+
 /* ---- a10 fused: x += linear2(GELU(dwconv3x3(h1)))  (LeFF second half, model.py:674-683, :987) ----
  * h1 T[B][H][W][4C] = GELU(linear1(LN2(x))); w9 f32[9][4C]; bdw f32[4C]; W2_fm fragment-major T[C][4C]; b2 f32[C];
  * x f32 rows of C (stride ld), updated in place.  The conv output never reaches HBM. */
@@ -215,6 +224,14 @@ int uf_output_proj_fwd(const float* x, int ld_x, const float* w, const float* bi
 int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype dtype, void* stream);
 /* y = GELU(a) as a separate pass, for a training forward that keeps the pre-activation (same flavour as the fused epilogues) */
 int uf_gelu_fwd(const void* a, void* y, long long n, uf_dtype dtype, void* stream);
+/* training forms of uf_linear_fwd (uformer_amd/train.py):
+ *   uf_linear_pre_gelu_fwd: out = a = A W^T + bias AND act_out = GELU(a as stored): linear1 of the LeFF in one pass (model.py:657-658);
+ *   uf_linear_mul_dgelu: out = T(A W^T + bias) * GELU'(pre[m][n]): the input gradient of a Linear whose input came out of a GELU
+ *     (A = dy, W = the layer's weight transposed, bias = zeros): uf_linear_fwd + uf_gelu_bwd in one pass. */
+int uf_linear_pre_gelu_fwd(const void* A, const void* W, const float* bias, void* out, void* act_out, int M, int N, int K,
+                           uf_dtype dtype, void* stream);
+int uf_linear_mul_dgelu(const void* A, const void* W, const float* bias, const void* pre, void* out, int M, int N, int K,
+                        uf_dtype dtype, void* stream);
 /* nn.LayerNorm(C) backward over rows of the f32 stream: dx f32[rows][ld_dx]; dgamma, dbeta f32[C] are OVERWRITTEN
  * with the sums over all rows.  C in {16,32,64,128,256,512,1024}. */
 size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);
@@ -260,6 +277,20 @@ int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, int H, int W
               int nchw, uf_dtype dtype, void* stream);
 int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B, int H, int W, int Cin, int k, int stride, int pad,
               int nchw, int accumulate, uf_dtype dtype, void* stream);
+
+/* streaming helpers of the block's recompute / backward; each replaces several elementwise passes (cast, DropPath scale, window
+ * permutation, residual add, head merge).  Rows of C channels, C % 8 == 0; scale = f32[B] per-image DropPath scale or NULL.
+ *   uf_residual_combine: out[tok] = (a ? a[tok] : 0) + scale[img] * b[row]; b is T (or f32 when b_is_f32) in WINDOW order when
+ *     `windowed` (window_reverse + roll back, model.py:975-980), else raster; a, out f32 raster.  (x1 = x + DropPath(attn branch).)
+ *   uf_grad_fork: t = g1[tok] (+ g2[tok]); sum_out[tok] = t (optional); cast_out[row] = T(t * scale[img]), row = window order when
+ *     `windowed` (roll + window_partition, model.py:957-963).  (gradient entering a branch, cast to the GEMM operand type.)
+ *   uf_qkv_grad_merge: dqkv T[n_windows*64][3C] from uf_window_attention_bwd's dq (x head_dim^-0.5), dk, dvt (head merge). */
+int uf_residual_combine(const float* a, const void* b, int b_is_f32, float* out, const float* scale, int B, int H, int W,
+                        int C, int windowed, int shift, uf_dtype dtype, void* stream);
+int uf_grad_fork(const float* g1, const float* g2, float* sum_out, void* cast_out, const float* scale, int B, int H, int W,
+                 int C, int windowed, int shift, uf_dtype dtype, void* stream);
+int uf_qkv_grad_merge(const void* dq, const void* dk, const void* dvt, void* dqkv, int n_windows, int heads, int head_dim,
+                      uf_dtype dtype, void* stream);
 
 /* ---- f-2: training-step tail ------------------------------------------------------------------------------
  * CharbonnierLoss.forward + its gradient in one pass (losses.py:41-52; criterion of train/train_denoise.py:164,181):

@@ -308,3 +308,67 @@ def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_grad_B_{'f32' if f32 else 'bf16'}.json", "w") as f:
         json.dump(worst, f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (4096, 128, 32), (130, 2048, 512)])
+def test_fused_training_gemm_epilogues_equal_the_two_pass_forms(dtype, M, N, K):
+    """uf_linear_pre_gelu_fwd == uf_linear_fwd then uf_gelu_fwd; uf_linear_mul_dgelu == uf_linear_fwd then uf_gelu_bwd: the fused
+    stores apply the activation / its derivative to the value AS STORED, so the results are bit-identical to the two-pass forms."""
+    from uformer_amd import ops
+    a = torch.randn(M, K, generator=g(60)).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g(61)) * K ** -0.5).to(dtype).cuda()
+    b = (torch.randn(N, generator=g(62)) * 0.1).cuda()
+    pre0 = ops.linear(a, w, b)
+    pre, act = ops.linear_pre_gelu(a, w, b)
+    assert torch.equal(pre, pre0) and torch.equal(act, ops.gelu(pre0))
+    c = (torch.randn(M, N, generator=g(63)) * 2).to(dtype).cuda()
+    zero = torch.zeros(N, device="cuda")
+    assert torch.equal(ops.linear_mul_dgelu(a, w, zero, c), ops.gelu_bwd(c, ops.linear(a, w, zero)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32)])
+def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):
+    from uformer_amd import ops
+    h = torch.randn(B, H, W, C, generator=g(64)).to(dtype).cuda()
+    a = (torch.randn(B, H, W, C, generator=g(65)) * 2).to(dtype).cuda()
+    w9 = (torch.randn(9, C, generator=g(66)) * 0.3).cuda()
+    bias = (torch.randn(C, generator=g(67)) * 0.1).cuda()
+    pre0 = ops.dwconv3x3(h, w9, bias, gelu=False)
+    pre, act = ops.dwconv3x3_pre_gelu(h, w9, bias)
+    assert torch.equal(pre, pre0) and torch.equal(act, ops.gelu(pre0))
+    flip = w9.flip(0).contiguous()
+    assert torch.equal(ops.dwconv3x3_mul_dgelu(h, flip, a), ops.gelu_bwd(a, ops.dwconv3x3(h, flip, None, gelu=False)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_backward_streaming_helpers(dtype, shift):
+    """uf_residual_combine / uf_grad_fork / uf_qkv_grad_merge against the ATen sequences they replace (window_reverse + cast +
+    per-sample scale + add;  add + scale + window_partition + cast;  head merge + query scale + cat)."""
+    from uformer_amd import ops
+    B, H, W, C, heads = 3, 16, 24, 64, 2
+    M, hd = B * H * W, C // heads
+    x = torch.randn(M, C, generator=g(70)).cuda()
+    yw = torch.randn(M, C, generator=g(71)).to(dtype).cuda()                      # window order
+    s = torch.tensor([0.0, 1.25, 1.25]).cuda()
+    st = s.repeat_interleave(H * W).reshape(M, 1)
+    ref = x + ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float() * st
+    assert torch.equal(ops.residual_combine(x, yw, s, B, H, W, windowed=True, shift=shift), ref)
+    assert torch.equal(ops.residual_combine(None, yw, None, B, H, W, windowed=True, shift=shift),
+                       ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float())
+    assert torch.equal(ops.residual_combine(x, yw, s, B, H, W), x + yw.float() * st)
+    g1, g2 = torch.randn(M, C, generator=g(72)).cuda(), torch.randn(M, C, generator=g(73)).cuda()
+    tot, out = ops.grad_fork(g1, g2, s, B, H, W, dtype, windowed=True, shift=shift, want_sum=True)
+    assert torch.equal(tot, g1 + g2)
+    assert torch.equal(out, ops.window_partition(((g1 + g2) * st).reshape(B, H, W, C), 8, shift).reshape(M, C).to(dtype))
+    none, out = ops.grad_fork(g1, None, None, B, H, W, dtype)
+    assert none is None and torch.equal(out, g1.to(dtype))
+    nW = M // 64
+    dq = torch.randn(nW, heads, 64, hd, generator=g(74)).to(dtype).cuda()
+    dk = torch.randn(nW, heads, 64, hd, generator=g(75)).to(dtype).cuda()
+    dvt = torch.randn(nW, heads, hd, 64, generator=g(76)).to(dtype).cuda()
+    merge = lambda t: t.reshape(nW, heads, 64, hd).permute(0, 2, 1, 3).reshape(M, C)      # noqa: E731
+    ref = torch.cat([merge(dq.float() * hd ** -0.5).to(dtype), merge(dk), merge(dvt.transpose(2, 3))], 1)
+    assert torch.equal(ops.qkv_grad_merge(dq, dk, dvt, heads), ref)

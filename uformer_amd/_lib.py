@@ -62,6 +62,10 @@ SIGNATURES = {
     "uf_dwconv3x3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "uf_gelu_bwd": (I, [P, P, P, C.c_longlong, I, P]),
     "uf_gelu_fwd": (I, [P, P, C.c_longlong, I, P]),
+    "uf_linear_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "uf_linear_mul_dgelu": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "uf_dwconv3x3_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "uf_dwconv3x3_mul_dgelu": (I, [P, P, P, P, I, I, I, I, I, P]),
     "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),
     "uf_layernorm_bwd": (I, [P, I, P, P, I, P, I, P, P, I, I, P, c_size_t, P]),
     "uf_linear_wgrad_workspace_bytes": (c_size_t, [I, I, I]),
@@ -85,6 +89,9 @@ SIGNATURES = {
     "uf_rpb_table_grad": (I, [P, P, I, P]),
     "uf_im2col": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "uf_col2im": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "uf_residual_combine": (I, [P, P, I, P, P, I, I, I, I, I, I, I, P]),
+    "uf_grad_fork": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
+    "uf_qkv_grad_merge": (I, [P, P, P, P, I, I, I, I, P]),
     "uf_charbonnier_workspace_bytes": (c_size_t, [C.c_longlong]),
     "uf_charbonnier_fwd_bwd": (I, [P, P, P, P, C.c_longlong, C.c_float, C.c_float, P, c_size_t, P]),
     "uf_adamw_step": (I, [P, P, P, P, P, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, C.c_double, P]),

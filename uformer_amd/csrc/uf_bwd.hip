@@ -1025,3 +1025,128 @@ extern "C" int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B
     else hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate);
     return check_launch("col2im");
 }
+
+// ===============================================================================================================================
+// Streaming helpers of the block's recompute / backward (every one replaces 2-5 ATen elementwise passes: cast, per-sample DropPath
+// scale, window_partition / window_reverse, residual add, head merge).  8 channels per thread, rows of C channels (C % 8 == 0).
+// ===============================================================================================================================
+namespace uf {
+namespace {
+
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
+template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float* f) { Vec<bf16>::load(p, f); }
+template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) { Vec<float>::load(p, f); Vec<float>::load(p + 4, f + 4); }
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
+template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float* f) { Vec<bf16>::store(p, f); }
+template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) { Vec<float>::store(p, f); Vec<float>::store(p + 4, f + 4); }
+
+// out[tok] = (a ? a[tok] : 0) + s(tok) * b[row],  row = the window-order index of tok when `windowed` (b is in window order: this
+// is window_reverse + roll back, model.py:975-980), else tok;  s = scale[image of tok] or 1.
+template <typename TB>
+__global__ __launch_bounds__(256) void residual_combine_kernel(const float* __restrict__ a, const TB* __restrict__ b, float* __restrict__ out, const float* __restrict__ scale,
+                                                               int B, int H, int W, int C, int windowed, int shift) {
+    const int cv = C / 8;
+    const long long total = (long long)B * H * W * cv;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int c8 = (int)(t % cv) * 8;
+        const int row = (int)(t / cv);                                             // index into b
+        const int tok = windowed ? window_row_to_token(row, H, W, shift) : row;  // index into a / out
+        const float s = scale ? scale[tok / (H * W)] : 1.0f;
+        float fb[8], fa[8];
+        load8<TB>(b + (size_t)row * C + c8, fb);
+        if (a) load8<float>(a + (size_t)tok * C + c8, fa);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[e] = (a ? fa[e] : 0.f) + s * fb[e];
+        store8<float>(out + (size_t)tok * C + c8, fb);
+    }
+}
+
+// t = g1[tok] (+ g2[tok]);  sum_out[tok] = t (optional);  cast_out[row] = T(t * s(tok)),  row = window-order index of tok when
+// `windowed` (roll + window_partition, model.py:957-963), else tok.
+template <typename TO>
+__global__ __launch_bounds__(256) void grad_fork_kernel(const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ sum_out, TO* __restrict__ cast_out,
+                                                        const float* __restrict__ scale, int B, int H, int W, int C, int windowed, int shift) {
+    const int cv = C / 8;
+    const long long total = (long long)B * H * W * cv;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int c8 = (int)(t % cv) * 8;
+        const int row = (int)(t / cv);
+        const int tok = windowed ? window_row_to_token(row, H, W, shift) : row;
+        const float s = scale ? scale[tok / (H * W)] : 1.0f;
+        float f[8], f2[8];
+        load8<float>(g1 + (size_t)tok * C + c8, f);
+        if (g2) {
+            load8<float>(g2 + (size_t)tok * C + c8, f2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] += f2[e];
+        }
+        if (sum_out) store8<float>(sum_out + (size_t)tok * C + c8, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] *= s;
+        store8<TO>(cast_out + (size_t)row * C + c8, f);
+    }
+}
+
+// dqkv[m][0..3C) in window-row order from the attention backward's per-(window, head) tensors:
+//   [0,C)   = dq[w][h][t][d] * qscale      (dq is the gradient wrt the SCALED query: model.py:497)
+//   [C,2C)  = dk[w][h][t][d]               [2C,3C) = dvt[w][h][d][t]      with m = w*64 + t, channel = h*32 + d
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_grad_merge_kernel(const T* __restrict__ dq, const T* __restrict__ dk, const T* __restrict__ dvt, T* __restrict__ out,
+                                                             int n_windows, int heads, float qscale) {
+    const int C = heads * 32;
+    const long long total = (long long)n_windows * 64 * heads * 12;      // 8-channel pieces: 3 parts x heads x 4 per row
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int piece = (int)(t % (heads * 12));
+        const long long m = t / (heads * 12);
+        const int part = piece / (heads * 4), hp = piece - part * heads * 4, h = hp >> 2, d0 = (hp & 3) * 8;
+        const int w = (int)(m >> 6), tk = (int)(m & 63);
+        float f[8];
+        if (part < 2) {
+            load8<T>((part == 0 ? dq : dk) + (((size_t)w * heads + h) * 64 + tk) * 32 + d0, f);
+            if (part == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] *= qscale;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = load1(dvt + (((size_t)w * heads + h) * 32 + d0 + e) * 64 + tk);
+        }
+        store8<T>(out + (size_t)m * 3 * C + part * C + h * 32 + d0, f);
+    }
+}
+
+}  // namespace
+}  // namespace uf
+
+extern "C" int uf_residual_combine(const float* a, const void* b, int b_is_f32, float* out, const float* scale, int B, int H, int W, int C, int windowed, int shift,
+                                   uf_dtype dtype, void* stream) {
+    UF_REQUIRE(b && out, UF_ERR_NULL, "uf_residual_combine: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && (!windowed || (H % 8 == 0 && W % 8 == 0)), UF_ERR_SHAPE, "uf_residual_combine: B=%d H=%d W=%d C=%d", B, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d((long long)B * H * W * (C / 8));
+    if (b_is_f32 || dtype == UF_F32) hipLaunchKernelGGL(residual_combine_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)b, out, scale, B, H, W, C, windowed, shift);
+    else hipLaunchKernelGGL(residual_combine_kernel<bf16>, dim3(grid), dim3(256), 0, st, a, (const bf16*)b, out, scale, B, H, W, C, windowed, shift);
+    return check_launch("residual_combine");
+}
+
+extern "C" int uf_grad_fork(const float* g1, const float* g2, float* sum_out, void* cast_out, const float* scale, int B, int H, int W, int C, int windowed, int shift,
+                            uf_dtype dtype, void* stream) {
+    UF_REQUIRE(g1 && cast_out, UF_ERR_NULL, "uf_grad_fork: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && (!windowed || (H % 8 == 0 && W % 8 == 0)), UF_ERR_SHAPE, "uf_grad_fork: B=%d H=%d W=%d C=%d", B, H, W, C);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d((long long)B * H * W * (C / 8));
+    if (dtype == UF_F32) hipLaunchKernelGGL(grad_fork_kernel<float>, dim3(grid), dim3(256), 0, st, g1, g2, sum_out, (float*)cast_out, scale, B, H, W, C, windowed, shift);
+    else hipLaunchKernelGGL(grad_fork_kernel<bf16>, dim3(grid), dim3(256), 0, st, g1, g2, sum_out, (bf16*)cast_out, scale, B, H, W, C, windowed, shift);
+    return check_launch("grad_fork");
+}
+
+extern "C" int uf_qkv_grad_merge(const void* dq, const void* dk, const void* dvt, void* dqkv, int n_windows, int heads, int head_dim, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(dq && dk && dvt && dqkv, UF_ERR_NULL, "uf_qkv_grad_merge: null pointer");
+    UF_REQUIRE(n_windows > 0 && heads > 0 && head_dim == 32, UF_ERR_SHAPE, "uf_qkv_grad_merge: n_windows=%d heads=%d head_dim=%d (32)", n_windows, heads, head_dim);
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = grid1d((long long)n_windows * 64 * heads * 12);
+    const float qs = 1.0f / sqrtf((float)head_dim);
+    if (dtype == UF_F32) hipLaunchKernelGGL(qkv_grad_merge_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dvt, (float*)dqkv, n_windows, heads, qs);
+    else hipLaunchKernelGGL(qkv_grad_merge_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dq, (const bf16*)dk, (const bf16*)dvt, (bf16*)dqkv, n_windows, heads, qs);
+    return check_launch("qkv_grad_merge");
+}

@@ -111,9 +111,25 @@ template <> struct Vec16<float> {
 // once per (column tap) and feeds up to 3 output rows, the 3 column-tap weights live in registers.
 constexpr int DW_R = 4;
 
-template <typename T, bool ACT>   // ACT: + GELU (the LeFF forward); without it the same stencil serves the backward (flipped taps)
+// round N values to the operand type and back (what a later pass would read from memory)
+template <typename T, int N> __device__ __forceinline__ void round_to(float* f) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < N; i += 2) {
+            const unsigned pk = pack2bf(f[i], f[i + 1]);
+            f[i] = __uint_as_float(pk << 16); f[i + 1] = __uint_as_float(pk & 0xffff0000u);
+        }
+    }
+}
+__device__ __forceinline__ float dw_gelu_grad(float a) {   // GELU'(a), the expression of uf_gelu_bwd
+    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
+}
+
+// ACT 0: the bare stencil (also the backward: flipped taps);  1: + GELU (the LeFF forward);  2: out = pre-activation AND aux = GELU of
+// it as stored (training forward keeps both);  3: out = stencil (as stored) * GELU'(aux) (input gradient through the preceding GELU)
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict__ x, const float* __restrict__ w9,
-                                                             const float* __restrict__ bias, T* __restrict__ out, int B, int H,
+                                                             const float* __restrict__ bias, T* __restrict__ out, T* __restrict__ aux, int B, int H,
                                                              int W, int C) {
     constexpr int N = Vec16<T>::N;
     const int cv = C / N;
@@ -166,8 +182,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
     }
 #pragma unroll
     for (int r = 0; r < DW_R; ++r) {
-        if constexpr (ACT) gelu_n<T, N>(acc[r]);
-        Vec16<T>::store(out + ((size_t)(b * H + y0 + r) * W + xw) * C + c, acc[r]);
+        const size_t o = ((size_t)(b * H + y0 + r) * W + xw) * C + c;
+        if constexpr (ACT == 1) gelu_n<T, N>(acc[r]);
+        if constexpr (ACT == 3) {
+            float a[N];
+            Vec16<T>::load(aux + o, a);
+            round_to<T, N>(acc[r]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[r][i] *= dw_gelu_grad(a[i]);
+        }
+        Vec16<T>::store(out + o, acc[r]);
+        if constexpr (ACT == 2) {
+            round_to<T, N>(acc[r]);
+            gelu_n<T, N>(acc[r]);
+            Vec16<T>::store(aux + o, acc[r]);
+        }
     }
 }
 
@@ -424,31 +453,56 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
 // gelu != 0: depthwise 3x3 + bias + GELU (LeFF forward, model.py:659-660).  gelu == 0: the bare stencil (bias may be
 // NULL) -- with the taps flipped (w9[8 - t]) it is the INPUT gradient of the same convolution:
 // dh[y,x] = sum_{ky,kx} w[ky,kx] dc[y-ky+1, x-kx+1].
-extern "C" int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C, int gelu,
-                                uf_dtype dtype, void* stream) {
-    UF_REQUIRE(x && w9 && out && (bias || !gelu), UF_ERR_NULL, "uf_dwconv3x3_fwd: null pointer");
-    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: bad shape (H must be a multiple of %d)", DW_R);
+namespace {
+template <typename T, int ACT>
+void launch_dwconv(const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, hipStream_t st) {
+    constexpr int N = Vec16<T>::N;
+    const long long n = (long long)B * (H / DW_R) * W * (C / N);
+    hipLaunchKernelGGL((dwconv3x3_gelu_kernel<T, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const T*)x, w9, bias, (T*)out, (T*)aux, B, H, W, C);
+}
+// mode: 0 plain, 1 + GELU, 2 pre-activation + GELU (two outputs), 3 * GELU'(aux)
+int dwconv_any(const char* fn, const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, int mode, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w9 && out && (bias || mode == 0 || mode == 3) && (aux || mode < 2), UF_ERR_NULL, "%s: null pointer", fn);
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "%s: bad shape (H must be a multiple of %d)", fn, DW_R);
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
+    UF_REQUIRE(C % (dtype == UF_BF16 ? 8 : 4) == 0, UF_ERR_SHAPE, "%s: C=%d must be a multiple of %d", fn, C, dtype == UF_BF16 ? 8 : 4);
     hipStream_t st = (hipStream_t)stream;
     char tname[64] = "";
-    if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3%s %dx%d", gelu ? "_gelu" : "", B * H * W, C);
-    ScopedTimer tm(tname, 18.0 * B * H * W * C, 2.0 * B * H * W * C * dtype_size(dtype), st);
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3_m%d %dx%d", mode, B * H * W, C);
+    ScopedTimer tm(tname, 18.0 * B * H * W * C, (mode >= 2 ? 3.0 : 2.0) * B * H * W * C * dtype_size(dtype), st);
     if (dtype == UF_BF16) {
-        UF_REQUIRE(C % 8 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: C=%d must be a multiple of 8", C);
-        const long long n = (long long)B * (H / DW_R) * W * (C / 8);
-        const dim3 grid((unsigned)((n + 255) / 256));
-        if (gelu) hipLaunchKernelGGL((dwconv3x3_gelu_kernel<bf16, true>), grid, dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
-        else hipLaunchKernelGGL((dwconv3x3_gelu_kernel<bf16, false>), grid, dim3(256), 0, st, (const bf16*)x, w9, bias, (bf16*)out, B, H, W, C);
-    } else if (dtype == UF_F32) {
-        UF_REQUIRE(C % 4 == 0, UF_ERR_SHAPE, "uf_dwconv3x3_fwd: C=%d must be a multiple of 4", C);
-        const long long n = (long long)B * (H / DW_R) * W * (C / 4);
-        const dim3 grid((unsigned)((n + 255) / 256));
-        if (gelu) hipLaunchKernelGGL((dwconv3x3_gelu_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
-        else hipLaunchKernelGGL((dwconv3x3_gelu_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, w9, bias, (float*)out, B, H, W, C);
+        switch (mode) {
+            case 0: launch_dwconv<bf16, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 1: launch_dwconv<bf16, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 2: launch_dwconv<bf16, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            default: launch_dwconv<bf16, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
+        }
     } else {
-        set_error("uf_dwconv3x3_fwd: dtype %d", (int)dtype);
-        return UF_ERR_UNSUPPORTED;
+        switch (mode) {
+            case 0: launch_dwconv<float, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 1: launch_dwconv<float, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 2: launch_dwconv<float, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            default: launch_dwconv<float, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
+        }
     }
     return check_launch("dwconv3x3");
+}
+}  // namespace
+
+extern "C" int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C, int gelu,
+                                uf_dtype dtype, void* stream) {
+    return dwconv_any("uf_dwconv3x3_fwd", x, w9, bias, out, nullptr, B, H, W, C, gelu ? 1 : 0, dtype, stream);
+}
+
+// training forms (uformer_amd/train.py): the stencil with its pre-activation AND GELU written in one pass (model.py:672-674), and
+// the input-gradient stencil (flipped taps, no bias) times GELU'(pre) of the GELU in front of the convolution (model.py:657-658).
+extern "C" int uf_dwconv3x3_pre_gelu_fwd(const void* x, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H, int W, int C,
+                                         uf_dtype dtype, void* stream) {
+    return dwconv_any("uf_dwconv3x3_pre_gelu_fwd", x, w9, bias, pre_out, act_out, B, H, W, C, 2, dtype, stream);
+}
+
+extern "C" int uf_dwconv3x3_mul_dgelu(const void* dy, const float* w9_flipped, const void* pre, void* out, int B, int H, int W, int C, uf_dtype dtype, void* stream) {
+    return dwconv_any("uf_dwconv3x3_mul_dgelu", dy, w9_flipped, nullptr, out, const_cast<void*>(pre), B, H, W, C, 3, dtype, stream);
 }
 
 extern "C" int uf_dwconv3x3_gelu_fwd(const void* x, const float* w9, const float* bias, void* out, int B, int H, int W, int C,

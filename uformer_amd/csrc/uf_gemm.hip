@@ -74,6 +74,24 @@ struct WChunk {
     __device__ __forceinline__ u32x4 finish() const { return ok ? v : u32x4{0, 0, 0, 0}; }
 };
 
+template <typename T> __device__ __forceinline__ void unpack_chunk(u32x4 v, float* f) {
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(v[i] << 16); f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
+    }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* f) {
+    if constexpr (sizeof(T) == 2) return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+    else return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+}
+// GELU'(a) = Phi(a) + a phi(a)   (nn.GELU erf form; the same expression as uf_gelu_bwd)
+__device__ __forceinline__ float gelu_grad(float a) {
+    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
+}
+
 template <typename T, int EP>
 __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x4 acc) {
     if constexpr (EP == E_RES_WINREV || EP == E_RES) {
@@ -186,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         __syncthreads();
     }
 
-    constexpr bool STAGED = (EP == E_STORE_T || EP == E_STORE_T_GELU || EP == E_QKV);
+    constexpr bool STAGED = (EP == E_STORE_T || EP == E_STORE_T_GELU || EP == E_QKV || EP == E_STORE_T_PRE_GELU || EP == E_STORE_T_MUL_DGELU);
     if constexpr (STAGED) {
         // T-typed outputs: stage the wave's tile in LDS (the main-loop buffers are free after the
         // last barrier) and copy it out in 16-byte chunks so that every store instruction writes whole
@@ -245,6 +263,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     } else {
                         dst = reinterpret_cast<T*>(p.out) + (size_t)m * p.ldo + n;
                     }
+                    if constexpr (EP == E_STORE_T_PRE_GELU) {       // the activation of the value AS STORED (what a separate pass would read)
+                        float f[EPC];
+                        unpack_chunk<T>(val, f);
+                        gelu_n<T, EPC>(f);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(p.aux) + (size_t)m * p.ldo + n) = pack_chunk<T>(f);
+                    }
+                    if constexpr (EP == E_STORE_T_MUL_DGELU) {      // dy (rounded to T, as a separate pass would read it) * GELU'(a)
+                        float f[EPC], a[EPC];
+                        unpack_chunk<T>(val, f);
+                        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldo + n), a);
+#pragma unroll
+                        for (int e = 0; e < EPC; ++e) f[e] *= gelu_grad(a[e]);
+                        *reinterpret_cast<u32x4*>(dst) = pack_chunk<T>(f);
+                    } else
                     *reinterpret_cast<u32x4*>(dst) = val;
                 }
             }
@@ -314,6 +346,8 @@ int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
             case E_STORE_T: return launch_bn<T, A_PLAIN, E_STORE_T>(p, stream);
             case E_STORE_T_GELU: return launch_bn<T, A_PLAIN, E_STORE_T_GELU>(p, stream);
             case E_QKV: return launch_bn<T, A_PLAIN, E_QKV>(p, stream);
+            case E_STORE_T_PRE_GELU: return launch_bn<T, A_PLAIN, E_STORE_T_PRE_GELU>(p, stream);
+            case E_STORE_T_MUL_DGELU: return launch_bn<T, A_PLAIN, E_STORE_T_MUL_DGELU>(p, stream);
             case E_RES_WINREV: return launch_bn<T, A_PLAIN, E_RES_WINREV>(p, stream);
             case E_RES: return launch_bn<T, A_PLAIN, E_RES>(p, stream);
             default: break;
@@ -338,7 +372,8 @@ int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStre
                UF_ERR_ALIGN, "gemm: operands must be 16-byte aligned");
     if (aload == A_PLAIN) UF_REQUIRE(p.lda % epc == 0, UF_ERR_ALIGN, "gemm: lda=%d not a multiple of %d", p.lda, epc);
     else UF_REQUIRE(p.lda % 4 == 0, UF_ERR_ALIGN, "gemm: lda=%d not a multiple of 4", p.lda);
-    if (epi == E_STORE_T || epi == E_STORE_T_GELU || epi == E_QKV)
+    if (epi == E_STORE_T_PRE_GELU || epi == E_STORE_T_MUL_DGELU) UF_REQUIRE(p.aux && ((uintptr_t)p.aux % 16) == 0, UF_ERR_NULL, "gemm: this epilogue needs a 16-byte aligned aux operand");
+    if (epi == E_STORE_T || epi == E_STORE_T_GELU || epi == E_QKV || epi == E_STORE_T_PRE_GELU || epi == E_STORE_T_MUL_DGELU)
         UF_REQUIRE(p.N % epc == 0, UF_ERR_SHAPE, "gemm: N=%d must be a multiple of %d for this epilogue", p.N, epc);
     if (epi == E_QKV) {
         const int C = p.heads * p.hd;
@@ -363,6 +398,25 @@ extern "C" int uf_linear_fwd(const void* A, const void* W, const float* bias, vo
     UF_REQUIRE(out, UF_ERR_NULL, "uf_linear_fwd: null out");
     UF_REQUIRE(act == 0 || act == 1, UF_ERR_UNSUPPORTED, "uf_linear_fwd: act must be 0 or 1");
     return uf::launch_gemm(p, uf::A_PLAIN, act ? uf::E_STORE_T_GELU : uf::E_STORE_T, dtype, (hipStream_t)stream);
+}
+
+// training forms of the projection GEMM (uformer_amd/train.py):
+//   uf_linear_pre_gelu_fwd: out = a = A W^T + bias AND act_out = GELU(a as stored)  -- linear1 of the LeFF keeps the pre-activation
+//     for GELU' and the activation for the depthwise stencil, one pass instead of GEMM + uf_gelu_fwd      (model.py:657-658)
+//   uf_linear_mul_dgelu: out = T(A W^T) * GELU'(pre)  -- the input gradient of a Linear whose INPUT came out of a GELU: the GEMM of
+//     uf_linear_fwd(dy, W^T) with uf_gelu_bwd folded into its store (W here is the transposed weight, (N=K_layer, K=N_layer)).
+extern "C" int uf_linear_pre_gelu_fwd(const void* A, const void* W, const float* bias, void* out, void* act_out, int M, int N, int K, uf_dtype dtype, void* stream) {
+    uf::GemmParams p{};
+    p.A = A; p.lda = K; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = N; p.aux = act_out;
+    UF_REQUIRE(out && act_out, UF_ERR_NULL, "uf_linear_pre_gelu_fwd: null out");
+    return uf::launch_gemm(p, uf::A_PLAIN, uf::E_STORE_T_PRE_GELU, dtype, (hipStream_t)stream);
+}
+
+extern "C" int uf_linear_mul_dgelu(const void* A, const void* W, const float* bias, const void* pre, void* out, int M, int N, int K, uf_dtype dtype, void* stream) {
+    uf::GemmParams p{};
+    p.A = A; p.lda = K; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = N; p.aux = const_cast<void*>(pre);
+    UF_REQUIRE(out && pre, UF_ERR_NULL, "uf_linear_mul_dgelu: null pointer");
+    return uf::launch_gemm(p, uf::A_PLAIN, uf::E_STORE_T_MUL_DGELU, dtype, (hipStream_t)stream);
 }
 
 extern "C" int uf_qkv_fwd(const void* A, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int M,

@@ -12,7 +12,9 @@ enum Epi {
     E_RES_WINREV = 3,   // out f32[tok(m)][n] = resid[tok(m)][n] + acc + bias  (window_reverse + unroll)
     E_RES = 4,          // out f32[m][n] = resid[m][n] + acc + bias
     E_STORE_R = 5,      // out f32[m][n] = acc + bias
-    E_UPSAMPLE = 6      // ConvTranspose2d k2 s2 scatter into (2H,2W)
+    E_UPSAMPLE = 6,     // ConvTranspose2d k2 s2 scatter into (2H,2W)
+    E_STORE_T_PRE_GELU = 7,  // out T[m][n] = a = acc + bias AND aux T[m][n] = gelu(a as stored)  (training: linear1 keeps both)
+    E_STORE_T_MUL_DGELU = 8  // out T[m][n] = T(acc + bias) * GELU'(aux[m][n])                   (input gradient through a GELU)
 };
 
 struct GemmParams {
@@ -26,6 +28,7 @@ struct GemmParams {
     const float* resid; int ldr;
     void* q; void* k; void* vt; int heads, hd; float qscale;
     int Cout;
+    void* aux;                  // E_STORE_T_PRE_GELU: second output; E_STORE_T_MUL_DGELU: the pre-activation (read); ld = ldo
 };
 
 // dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.

@@ -239,6 +239,57 @@ def dwconv3x3(x: Tensor, w9: Tensor, bias: Optional[Tensor] = None, gelu: bool =
     return out
 
 
+def dwconv3x3_pre_gelu(x: Tensor, w9: Tensor, bias: Tensor) -> Tuple[Tensor, Tensor]:
+    """(pre, GELU(pre)) of the depthwise stencil in one pass (training forward keeps both)."""
+    _dev(x, w9, bias)
+    x = _c(x)
+    B, H, W, Cc = x.shape
+    pre, act = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().uf_dwconv3x3_pre_gelu_fwd(_ptr(x), _ptr(_c(w9, torch.float32)), _ptr(_c(bias, torch.float32)), _ptr(pre), _ptr(act),
+                                                         B, H, W, Cc, uf_dtype(x.dtype), _stream()), "uf_dwconv3x3_pre_gelu_fwd")
+    return pre, act
+
+
+def dwconv3x3_mul_dgelu(dy: Tensor, w9_flipped: Tensor, pre: Tensor) -> Tensor:
+    """Gradient through the depthwise conv and the GELU in front of it: stencil(dy; flipped taps) * GELU'(pre)."""
+    _dev(dy, w9_flipped, pre)
+    dy, pre = _c(dy), _c(pre, dy.dtype)
+    B, H, W, Cc = dy.shape
+    out = torch.empty_like(dy)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().uf_dwconv3x3_mul_dgelu(_ptr(dy), _ptr(_c(w9_flipped, torch.float32)), _ptr(pre), _ptr(out), B, H, W, Cc,
+                                                      uf_dtype(dy.dtype), _stream()), "uf_dwconv3x3_mul_dgelu")
+    return out
+
+
+def linear_pre_gelu(a: Tensor, w: Tensor, bias: Tensor) -> Tuple[Tensor, Tensor]:
+    """(a W^T + bias, GELU of it) in one pass; both T(M, N)."""
+    _dev(a, w, bias)
+    a, w = _c(a), _c(w, a.dtype)
+    M, K = a.shape
+    N = w.shape[0]
+    pre = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    act = torch.empty_like(pre)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_linear_pre_gelu_fwd(_ptr(a), _ptr(w), _ptr(_c(bias, torch.float32)), _ptr(pre), _ptr(act), M, N, K, uf_dtype(a.dtype), _stream()),
+                   "uf_linear_pre_gelu_fwd")
+    return pre, act
+
+
+def linear_mul_dgelu(dy: Tensor, w_t: Tensor, zero_bias: Tensor, pre: Tensor) -> Tensor:
+    """(dy @ w_t.T) * GELU'(pre): input gradient of a Linear fed by a GELU; w_t (K_layer, N_layer) is the transposed weight."""
+    _dev(dy, w_t, pre)
+    dy, w_t, pre = _c(dy), _c(w_t, dy.dtype), _c(pre, dy.dtype)
+    M, K = dy.shape
+    N = w_t.shape[0]
+    out = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(_lib.load().uf_linear_mul_dgelu(_ptr(dy), _ptr(w_t), _ptr(_c(zero_bias, torch.float32)), _ptr(pre), _ptr(out), M, N, K, uf_dtype(dy.dtype), _stream()),
+                   "uf_linear_mul_dgelu")
+    return out
+
+
 def gelu(a: Tensor) -> Tensor:
     """GELU(a) as a separate pass (nn.GELU, model.py:657-660); bf16 / f32."""
     _dev(a)
@@ -557,6 +608,50 @@ def rows_sum(x: Tensor) -> Tensor:
     ws = _ws(nbytes, x.device)
     with torch.cuda.device(x.device):
         _lib.check(lib.uf_rows_sum(_ptr(x), N, _ptr(out), M, N, dt, _ptr(ws), nbytes, _stream()), "uf_rows_sum")
+    return out
+
+
+def residual_combine(a: Optional[Tensor], b: Tensor, scale: Optional[Tensor], B: int, H: int, W: int, windowed: bool = False, shift: int = 0) -> Tensor:
+    """f32 (B*H*W, C) = (a or 0) + scale[image] * b; b (bf16/f32 rows) is in WINDOW order when ``windowed`` (window_reverse + roll
+    back folded in), ``scale`` = f32 (B,) DropPath scales or None."""
+    _dev(b)
+    b = _c(b)
+    C = b.shape[-1]
+    out = torch.empty(B * H * W, C, dtype=torch.float32, device=b.device)
+    a = None if a is None else _c(a, torch.float32)
+    scale = None if scale is None else _c(scale, torch.float32)
+    with torch.cuda.device(b.device):
+        _lib.check(_lib.load().uf_residual_combine(_ptr(a), _ptr(b), int(b.dtype == torch.float32), _ptr(out), _ptr(scale), B, H, W, C, int(windowed), shift,
+                                                   uf_dtype(b.dtype), _stream()), "uf_residual_combine")
+    return out
+
+
+def grad_fork(g1: Tensor, g2: Optional[Tensor], scale: Optional[Tensor], B: int, H: int, W: int, dtype, windowed: bool = False, shift: int = 0,
+              want_sum: bool = False) -> Tuple[Optional[Tensor], Tensor]:
+    """t = g1 (+ g2) (f32 raster rows); returns (t if ``want_sum`` else None, (t * scale[image]) cast to ``dtype``, in window order
+    when ``windowed``)."""
+    _dev(g1)
+    g1 = _c(g1, torch.float32)
+    g2 = None if g2 is None else _c(g2, torch.float32)
+    C = g1.shape[-1]
+    scale = None if scale is None else _c(scale, torch.float32)
+    tot = torch.empty_like(g1) if want_sum else None
+    out = torch.empty(B * H * W, C, dtype=dtype, device=g1.device)
+    with torch.cuda.device(g1.device):
+        _lib.check(_lib.load().uf_grad_fork(_ptr(g1), _ptr(g2), _ptr(tot), _ptr(out), _ptr(scale), B, H, W, C, int(windowed), shift, uf_dtype(dtype), _stream()),
+                   "uf_grad_fork")
+    return tot, out
+
+
+def qkv_grad_merge(dq: Tensor, dk: Tensor, dvt: Tensor, heads: int) -> Tensor:
+    """(n_windows*64, 3C) gradient of the fused q|k|v projection output from uf_window_attention_bwd's per-head tensors."""
+    _dev(dq)
+    dq, dk, dvt = _c(dq), _c(dk), _c(dvt)
+    hd = dq.shape[-1]
+    nW = dq.numel() // (heads * 64 * hd)
+    out = torch.empty(nW * 64, 3 * heads * hd, dtype=dq.dtype, device=dq.device)
+    with torch.cuda.device(dq.device):
+        _lib.check(_lib.load().uf_qkv_grad_merge(_ptr(dq), _ptr(dk), _ptr(dvt), _ptr(out), nW, heads, hd, uf_dtype(dq.dtype), _stream()), "uf_qkv_grad_merge")
     return out
 
 

@@ -72,10 +72,10 @@ class BlockPack:
 # LeWin block (model.py:908-989)
 # ------------------------------------------------------------------------------------------------------------------
 def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, dtype: torch.dtype,
-                        drop: Optional[Tensor] = None, pk: Optional[BlockPack] = None) -> Tuple[Tensor, Saved]:
+                        drop: Optional[Tensor] = None, pk: Optional[BlockPack] = None, need_y: bool = True) -> Tuple[Optional[Tensor], Saved]:
     """x: (B, L, C) f32 on the GPU -> (y, saved).  Op-by-op forward that keeps what the backward reads (also the RECOMPUTATION a
     block runs at the start of its backward).  ``drop``: None (eval) or (2, B) per-sample DropPath scales bernoulli(keep)/keep of
-    the two residual branches (model.py:986-987)."""
+    the two residual branches (model.py:986-987).  ``need_y=False``: the recomputation stops before linear2 (nothing reads y)."""
     B, L, C = x.shape
     H = W = int(math.sqrt(L))
     M = B * L
@@ -87,21 +87,20 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     q, k, vt = ops.qkv(xn, pk.wqkv, pk.bqkv, heads)                          # window rows; q already scaled
     o = ops.window_attention_core(q, k, vt, pk.bias, H=H, W=W, shift=shift)  # (M, C) window rows
     yw = ops.linear(o, pk.wp, f("attn.proj.bias"))
-    s1 = drop[0].float().repeat_interleave(L).reshape(M, 1) if drop is not None else None      # per-token copy of the per-sample scale
-    s2 = drop[1].float().repeat_interleave(L).reshape(M, 1) if drop is not None else None
-    br1 = ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float()
-    x1 = x2 + (br1 * s1 if s1 is not None else br1)
+    s1 = drop[0].float().contiguous() if drop is not None else None         # per-sample DropPath scales (B,)
+    s2 = drop[1].float().contiguous() if drop is not None else None
+    x1 = ops.residual_combine(x2, yw, s1, B, H, W, windowed=True, shift=shift)     # x + DropPath(window_reverse(proj))   model.py:975-986
     z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
-    a1 = ops.linear(z, pk.w1, f("mlp.linear1.0.bias"))                       # pre-activation, kept for GELU'
-    c_bias = f("mlp.dwconv.0.bias")
-    h1 = ops.gelu(a1).reshape(B, H, W, 4 * C)                                # one GEMM / one stencil + an elementwise GELU pass each
-    c = ops.dwconv3x3(h1, pk.w9, c_bias, gelu=False)                         # pre-activation of the second GELU
-    g2 = ops.gelu(c).reshape(M, 4 * C)
-    br2 = ops.linear(g2, pk.w2, f("mlp.linear2.0.bias")).float()
-    y = x1 + (br2 * s2 if s2 is not None else br2)
+    a1, h1 = ops.linear_pre_gelu(z, pk.w1, f("mlp.linear1.0.bias"))          # pre-activation (kept for GELU') and activation, one pass
+    h1 = h1.reshape(B, H, W, 4 * C)
+    c, g2 = ops.dwconv3x3_pre_gelu(h1, pk.w9, f("mlp.dwconv.0.bias"))        # likewise for the stencil and the second GELU
+    g2 = g2.reshape(M, 4 * C)
+    y = None
+    if need_y:
+        y = ops.residual_combine(x1, ops.linear(g2, pk.w2, f("mlp.linear2.0.bias")), s2, B, H, W).reshape(B, L, C)
     saved = dict(s1=s1, s2=s2, p=p, prefix=prefix, heads=heads, shift=shift, T=T, shape=(B, L, C), x2=x2, xn=xn, q=q, k=k, vt=vt, o=o, x1=x1, z=z, a1=a1,
                  h1=h1, c=c, g2=g2, pk=pk, mod=pk.mod is not None)
-    return y.reshape(B, L, C), saved
+    return y, saved
 
 
 def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
@@ -113,39 +112,36 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     f = lambda k: p[prefix + k]                                             # noqa: E731
     g: Grads = {}
     dyf = dy.reshape(M, C).float()
-    dyT = (dyf * sv["s2"] if sv["s2"] is not None else dyf).to(T).contiguous()      # gradient entering the (scaled) LeFF branch
+    _, dyT = ops.grad_fork(dyf, None, sv["s2"], B, H, W, T)                  # gradient entering the (scaled) LeFF branch, as a GEMM operand
     # LeFF: linear2 -> GELU -> depthwise -> GELU -> linear1                                   (model.py:666-685)
     g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = ops.linear_wgrad(dyT, sv["g2"])
     pk: BlockPack = sv["pk"]
-    dg2 = _input_grad(dyT, pk.w2_t)
-    dc = ops.gelu_bwd(sv["c"].reshape(M, 4 * C), dg2).reshape(B, H, W, 4 * C)
+    dc = ops.linear_mul_dgelu(dyT, pk.w2_t, _zeros(4 * C, dyT.device), sv["c"].reshape(M, 4 * C)).reshape(B, H, W, 4 * C)   # dY W2, times GELU'(c)
     dw9, g[prefix + "mlp.dwconv.0.bias"] = ops.dwconv3x3_wgrad(sv["h1"], dc)
     g[prefix + "mlp.dwconv.0.weight"] = dw9.t().reshape(4 * C, 1, 3, 3)
-    dh1 = ops.dwconv3x3(dc, pk.w9_flip, None, gelu=False)                      # input gradient = flipped-tap stencil
-    da1 = ops.gelu_bwd(sv["a1"], dh1.reshape(M, 4 * C))
+    da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
     g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = ops.linear_wgrad(da1, sv["z"])
     dz = _input_grad(da1, pk.w1_t).float()
     dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd(sv["x1"], f("norm2.weight"), dz)
-    dx1 = dx1 + dy.reshape(M, C).float()
     # attention half: proj -> attention -> qkv -> (+modulator) -> partition/roll -> LN1              (model.py:951-986)
-    dbr1 = dx1 * sv["s1"] if sv["s1"] is not None else dx1                          # gradient entering the (scaled) attention branch
-    dyw = ops.window_partition(dbr1.reshape(B, H, W, C), 8, shift).reshape(M, C).to(T)
+    # dx1 += dy (the residual), and the (scaled) gradient entering the attention branch in window order, in one pass
+    dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
     g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = ops.linear_wgrad(dyw, sv["o"])
     do = _input_grad(dyw, pk.wp_t)
     dq, dk, dvt, dbias = ops.window_attention_bwd(sv["q"], sv["k"], sv["vt"], pk.bias, do, H, W, shift)
     g[prefix + "attn.relative_position_bias_table"] = ops.rpb_table_grad(dbias)       # gather over the pairs of each table entry: deterministic
     nW = M // 64
-    merge = lambda t: t.reshape(nW, heads, 64, hd).permute(0, 2, 1, 3).reshape(M, C)      # noqa: E731  (nW,h,64,hd) -> rows
-    dqkv = torch.cat([merge(dq.float() * hd ** -0.5).to(T), merge(dk), merge(dvt.reshape(nW, heads, hd, 64).transpose(2, 3))], 1).contiguous()
+    dqkv = ops.qkv_grad_merge(dq, dk, dvt, heads)                                     # head merge + the query scale
     dWqkv, dbqkv = ops.linear_wgrad(dqkv, sv["xn"])
     g[prefix + "attn.qkv.to_q.weight"], g[prefix + "attn.qkv.to_kv.weight"] = dWqkv[:C], dWqkv[C:]
     g[prefix + "attn.qkv.to_q.bias"], g[prefix + "attn.qkv.to_kv.bias"] = dbqkv[:C], dbqkv[C:]
     dxn = _input_grad(dqkv, pk.wqkv_t)
     if sv["mod"]:                                                           # the (64, C) table is added to every window
         g[prefix + "modulator.weight"] = ops.rows_sum(dxn.reshape(nW, 64 * C)).reshape(64, C)
-    dln = ops.window_reverse(dxn.float().reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C)
+    dln = ops.residual_combine(None, dxn, None, B, H, W, windowed=True, shift=shift)  # window_reverse + roll back, to f32
     dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"] = ops.layernorm_bwd(sv["x2"], f("norm1.weight"), dln)
-    return (dx + dx1).reshape(B, L, C), g
+    dx = ops.residual_combine(dx, dx1, None, B, H, W, windowed=False)
+    return dx.reshape(B, L, C), g
 
 
 def lewin_block_forward_backward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, dy: Tensor,
@@ -262,7 +258,7 @@ class UformerTape:
                 sv = blocks.pop()                                                 # frees the block's saved input as the sweep passes it
                 if "x2" not in sv:                                                # recompute the intermediates from the block input
                     pk = sv["pk"]
-                    _, sv = lewin_block_forward(sv["x"].reshape(B, res[s] * res[s], C), sd, pk.prefix, pk.heads, pk.shift, T, sv["drop"], pk)
+                    _, sv = lewin_block_forward(sv["x"].reshape(B, res[s] * res[s], C), sd, pk.prefix, pk.heads, pk.shift, T, sv["drop"], pk, need_y=False)
                 d, gb = lewin_block_backward(sv, d)
                 del sv
                 g.update(gb)
