@@ -278,6 +278,15 @@ int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, int H, int W
 int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B, int H, int W, int Cin, int k, int stride, int pad,
               int nchw, int accumulate, uf_dtype dtype, void* stream);
 
+/* backward of the two full-resolution 3x3 stride-1 pad-1 convolutions, all f32 (InputProj 3 -> E with its LeakyReLU, model.py:771-800;
+ * OutputProj 2E -> 3, model.py:803-827).  Two forms: (token rows x, Cin % 4 == 0, Cout <= 4) and (x_nchw = 1: NCHW image, Cin <= 4,
+ * Cout 16, 32 or 64).  dy f32[B*H*W][Cout] token rows; act_out (InputProj form only, or NULL): the layer's stored OUTPUT rows, the
+ * gradient is first multiplied by LeakyReLU'(slope) taken from its sign; w (Cout,Cin,3,3) as in the state_dict.
+ * dx (NULL to skip) in the layout of x; dW (Cout,Cin,3,3); db (Cout).  Sums over pixels: per-block partials added in block order. */
+size_t uf_conv3x3_bwd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const float* act_out, float slope, const float* w, float* dx,
+                   float* dW, float* db, int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 /* streaming helpers of the block's recompute / backward; each replaces several elementwise passes (cast, DropPath scale, window
  * permutation, residual add, head merge).  Rows of C channels, C % 8 == 0; scale = f32[B] per-image DropPath scale or NULL.
  *   uf_residual_combine: out[tok] = (a ? a[tok] : 0) + scale[img] * b[row]; b is T (or f32 when b_is_f32) in WINDOW order when

@@ -372,3 +372,29 @@ def test_backward_streaming_helpers(dtype, shift):
     merge = lambda t: t.reshape(nW, heads, 64, hd).permute(0, 2, 1, 3).reshape(M, C)      # noqa: E731
     ref = torch.cat([merge(dq.float() * hd ** -0.5).to(dtype), merge(dk), merge(dvt.transpose(2, 3))], 1)
     assert torch.equal(ops.qkv_grad_merge(dq, dk, dvt, heads), ref)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,nchw", [(2, 24, 40, 3, 32, True), (1, 16, 16, 3, 16, True), (3, 8, 20, 4, 64, True),
+                                                  (2, 24, 40, 64, 3, False), (1, 16, 16, 32, 3, False), (5, 300, 12, 8, 4, False)])
+def test_conv3x3_bwd_direct_vs_torch_autograd(B, H, W, Cin, Cout, nchw):
+    """uf_conv3x3_bwd (InputProj form with LeakyReLU' from the stored output, OutputProj form) against torch autograd on the CPU."""
+    from uformer_amd import ops
+    x = torch.randn(B, Cin, H, W, generator=g(80), requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(81)) * 0.2).requires_grad_(True)
+    b = (torch.randn(Cout, generator=g(82)) * 0.1).requires_grad_(True)
+    dy = torch.randn(B, Cout, H, W, generator=g(83))
+    pre = F.conv2d(x, w, b, padding=1)
+    y = F.leaky_relu(pre, 0.01) if nchw else pre
+    y.backward(dy)
+    dy_rows = dy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda()
+    if nchw:
+        act = y.detach().permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().cuda()
+        dx, dW, db = ops.conv3x3_bwd(x.detach().cuda(), dy_rows, w.detach().cuda(), B, H, W, nchw=True, act_out=act, slope=0.01)
+        ref_dx = x.grad
+        none, dW2, db2 = ops.conv3x3_bwd(x.detach().cuda(), dy_rows, w.detach().cuda(), B, H, W, nchw=True, act_out=act, slope=0.01, need_dx=False)
+        assert none is None and torch.equal(dW, dW2) and torch.equal(db, db2)         # fixed summation order
+    else:
+        rows = x.detach().permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().cuda()
+        dx, dW, db = ops.conv3x3_bwd(rows, dy_rows, w.detach().cuda(), B, H, W)
+        ref_dx = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
+    assert rel(dx, ref_dx) < 2e-5 and rel(dW, w.grad) < 2e-5 and rel(db, b.grad) < 2e-5

@@ -89,6 +89,8 @@ SIGNATURES = {
     "uf_rpb_table_grad": (I, [P, P, I, P]),
     "uf_im2col": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "uf_col2im": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "uf_conv3x3_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I]),
+    "uf_conv3x3_bwd": (I, [P, I, P, P, C.c_float, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
     "uf_residual_combine": (I, [P, P, I, P, P, I, I, I, I, I, I, I, P]),
     "uf_grad_fork": (I, [P, P, P, P, P, I, I, I, I, I, I, I, P]),
     "uf_qkv_grad_merge": (I, [P, P, P, P, I, I, I, I, P]),

@@ -779,7 +779,11 @@ static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullpt
 static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     const int T = (dtype == UF_BF16 && wgrad_v2()) ? 128 : 64;
     const int tiles = ((N + T - 1) / T) * ((K + T - 1) / T), steps = (M + 31) / 32;
-    int S = 2048 / tiles;
+    // workgroups per launch to aim for: every chunk costs one N x K f32 partial written and read again by the ordered sum, so no more
+    // chunks than it takes to fill the chip (128-wide tiles: 2 workgroups per CU resident; UF_WGRAD_TARGET overrides, for A/B runs)
+    static const int target_env = getenv("UF_WGRAD_TARGET") ? atoi(getenv("UF_WGRAD_TARGET")) : 0;
+    const int target = target_env > 0 ? target_env : (T == 128 ? 1024 : 2048);
+    int S = target / tiles;
     if (S > steps) S = steps;
     if (S > 256) S = 256;
     return S < 1 ? 1 : S;
@@ -1145,8 +1149,226 @@ extern "C" int uf_qkv_grad_merge(const void* dq, const void* dk, const void* dvt
     UF_REQUIRE(n_windows > 0 && heads > 0 && head_dim == 32, UF_ERR_SHAPE, "uf_qkv_grad_merge: n_windows=%d heads=%d head_dim=%d (32)", n_windows, heads, head_dim);
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid1d((long long)n_windows * 64 * heads * 12);
-    const float qs = 1.0f / sqrtf((float)head_dim);
+    const float qs = (float)(1.0 / sqrt((double)head_dim));   // python: head_dim ** -0.5, rounded once to f32
     if (dtype == UF_F32) hipLaunchKernelGGL(qkv_grad_merge_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dvt, (float*)dqkv, n_windows, heads, qs);
     else hipLaunchKernelGGL(qkv_grad_merge_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dq, (const bf16*)dk, (const bf16*)dvt, (bf16*)dqkv, n_windows, heads, qs);
     return check_launch("qkv_grad_merge");
+}
+
+// ===============================================================================================================================
+// Backward of the two 3x3 stride-1 pad-1 convolutions at full resolution: InputProj (3 -> E, + LeakyReLU) and OutputProj (2E -> 3)
+// (model.py:771-800, :803-827).  One side has <= 4 channels, so these are streaming kernels, not GEMMs: the patch-matrix route
+// (uf_im2col + GEMMs + uf_col2im) moved ~10 GB per step for 0.7 % of the FLOPs.  All f32.
+//   dyeff[p][co] = dy[p][co] * (act ? (act[p][co] > 0 ? 1 : slope) : 1)           (LeakyReLU' from the stored OUTPUT of the stem)
+//   dx[q][ci]        = sum_{ky,kx,co} dyeff[q - (ky-1, kx-1)][co] * w[co][ci][ky][kx]
+//   dW[co][ci][ky][kx] = sum_p dyeff[p][co] * x[p + (ky-1, kx-1)][ci]             db[co] = sum_p dyeff[p][co]
+// ===============================================================================================================================
+namespace uf {
+namespace {
+
+constexpr int CB_MAXW = 2048;        // Cout * Cin * 9 of the two layers: 864 and 1728
+
+__device__ __forceinline__ float leaky_mask(const float* act, size_t i, float slope) { return act ? (act[i] > 0.f ? 1.f : slope) : 1.f; }   // torch: x > 0 ? g : g * slope; sign(out) = sign(x)
+
+// thread = (pixel q, group of 4 input channels).  Weights in LDS as wl[tap][co][ci].
+__global__ __launch_bounds__(256) void conv3x3_dx_kernel(const float* __restrict__ dy, const float* __restrict__ act, float slope, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int B, int H, int W, int Cin, int Cout, int nchw) {
+    __shared__ float wl[CB_MAXW];
+    for (int i = threadIdx.x; i < Cout * Cin * 9; i += 256) {          // w[co][ci][tap] -> wl[tap][co][ci]
+        const int tap = i % 9, ci = (i / 9) % Cin, co = i / (9 * Cin);
+        wl[(tap * Cout + co) * Cin + ci] = w[i];
+    }
+    __syncthreads();
+    const int groups = (Cin + 3) / 4;
+    const long long total = (long long)B * H * W * groups;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int grp = (int)(t % groups);
+        const long long q = t / groups;
+        const int xq = (int)(q % W), yq = (int)((q / W) % H), b = (int)(q / ((long long)W * H));
+        const int c0 = grp * 4, nc = Cin - c0 < 4 ? Cin - c0 : 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yp = yq - (ky - 1);
+            if (yp < 0 || yp >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int xp = xq - (kx - 1);
+                if (xp < 0 || xp >= W) continue;
+                const size_t p = ((size_t)b * H + yp) * W + xp;
+                const float* wt = wl + ((ky * 3 + kx) * Cout) * Cin + c0;
+                for (int co = 0; co < Cout; ++co) {
+                    const float d = dy[p * Cout + co] * leaky_mask(act, p * Cout + co, slope);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (e < nc) acc[e] = fmaf(d, wt[co * Cin + e], acc[e]);
+                }
+            }
+        }
+        if (nchw) {
+            for (int e = 0; e < nc; ++e) dx[(((size_t)b * Cin + c0 + e) * H + yq) * W + xq] = acc[e];
+        } else {
+            for (int e = 0; e < nc; ++e) dx[(size_t)q * Cin + c0 + e] = acc[e];
+        }
+    }
+}
+
+// Weight gradient, WIDE input side (OutputProj: Cin = 64, Cout = 3).  Block = 3 waves; wave = ky, lane (+64 j) = ci.  A thread walks
+// the columns u of input row y+ky-1 once: x[.][u][ci] is one coalesced load and meets dyeff[y][u+1-kx][co] for kx = 0..2 -- a
+// sliding window of wave-uniform values.  Partial sums of the block's rows go to partial[block][...] in the reference's
+// (Cout,Cin,3,3) order, then db (Cout values, lane 0 of wave 1); column_sum_kernel adds the blocks in order.
+template <int S>   // S = Cout <= 4
+__global__ __launch_bounds__(192) void conv3x3_wgrad_wide_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                                    int B, int H, int W, int Cin, int rows_per_block) {
+    const int ky = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int E = S * Cin * 9 + S;
+    float* out = partial + (size_t)blockIdx.x * E;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);
+    float dbs[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) dbs[s] = 0.f;
+    for (int cbase = 0; cbase < Cin; cbase += 64) {
+        const int ci = cbase + lane;
+        const bool live = ci < Cin;
+        float acc[S][3];
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+        for (int r = r0; r < r1; ++r) {
+            const int b = r / H, y = r - b * H;
+            const int yi = y + ky - 1;
+            if (yi < 0 || yi >= H) continue;                                  // wave-uniform
+            const float* xr = x + (((size_t)b * H + yi) * W) * Cin + (live ? ci : 0);
+            const float* dr = dy + (((size_t)b * H + y) * W) * S;
+            float d0[S], d1[S], d2[S];                                          // dyeff at columns u-1, u, u+1
+#pragma unroll
+            for (int s = 0; s < S; ++s) { d0[s] = 0.f; d1[s] = 0.f; d2[s] = dr[s]; }
+            // u = -1 (only kx = 0 would pair x[-1], which is padding): start at u = 0 with the window (dy[-1] = 0, dy[0], dy[1])
+#pragma unroll
+            for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = W > 1 ? dr[S + s] : 0.f; }
+#pragma unroll 4
+            for (int u = 0; u < W; ++u) {
+                const float xv = xr[(size_t)u * Cin];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {                                   // x column u = p.x + kx - 1  ->  p.x = u + 1 - kx
+                    acc[s][0] = fmaf(d2[s], xv, acc[s][0]);
+                    acc[s][1] = fmaf(d1[s], xv, acc[s][1]);
+                    acc[s][2] = fmaf(d0[s], xv, acc[s][2]);
+                }
+                if (cbase == 0 && ky == 1) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) dbs[s] += d1[s];
+                }
+#pragma unroll
+                for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = (u + 2 < W) ? dr[(size_t)(u + 2) * S + s] : 0.f; }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) out[((s * Cin + ci) * 3 + ky) * 3 + kx] = acc[s][kx];
+        }
+    }
+    if (ky == 1 && lane == 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) out[S * Cin * 9 + s] = dbs[s];
+    }
+}
+
+// Weight gradient, WIDE output side (InputProj: Cin = 3 NCHW image, Cout = 32, LeakyReLU' folded in).  Block = 3 waves; wave = ky;
+// lane = (pixel slot, co): a wave covers 64 / Cout pixels per step (Cout 16, 32 or 64).  dyeff[p][co] is the
+// coalesced load; the image values around p are the same address for all lanes of a pixel.  Partials as above.
+template <int S>   // S = Cin <= 4
+__global__ __launch_bounds__(192) void conv3x3_wgrad_wide_out_kernel(const float* __restrict__ img, const float* __restrict__ dy, const float* __restrict__ act, float slope,
+                                                                     float* __restrict__ partial, int B, int H, int W, int Cout, int rows_per_block) {
+    const int ky = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ppw = 64 / Cout;                                                 // pixels per wave step
+    const int co = lane % Cout, par = lane / Cout;
+    const int E = Cout * S * 9 + Cout;
+    float* out = partial + ((size_t)blockIdx.x * ppw + par) * E;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);
+    float acc[S][3], dbv = 0.f;
+#pragma unroll
+    for (int s = 0; s < S; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const int b = r / H, y = r - b * H;
+        const int yi = y + ky - 1;
+        const bool rowok = yi >= 0 && yi < H;                                   // wave-uniform
+        const size_t prow = ((size_t)b * H + y) * W;
+        const float* ir = img + ((size_t)b * S * H + (rowok ? yi : 0)) * W;     // plane s at + s*H*W
+#pragma unroll 2
+        for (int px = par; px < W; px += ppw) {
+            const size_t i = (prow + px) * Cout + co;
+            const float d = dy[i] * leaky_mask(act, i, slope);
+            if (ky == 1) dbv += d;
+            if (rowok) {
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float* pl = ir + (size_t)s * H * W + px;
+                    const float xl = px > 0 ? pl[-1] : 0.f, xc = pl[0], xr = px + 1 < W ? pl[1] : 0.f;
+                    acc[s][0] = fmaf(d, xl, acc[s][0]);
+                    acc[s][1] = fmaf(d, xc, acc[s][1]);
+                    acc[s][2] = fmaf(d, xr, acc[s][2]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) out[((co * S + s) * 3 + ky) * 3 + kx] = acc[s][kx];
+    if (ky == 1) out[Cout * S * 9 + co] = dbv;
+}
+
+}  // namespace
+}  // namespace uf
+
+static int conv3x3_bwd_blocks(int B, int H) { const int rows = B * H; return rows < 1024 ? rows : 1024; }
+
+extern "C" size_t uf_conv3x3_bwd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+    return (size_t)conv3x3_bwd_blocks(B, H) * 4 * ((size_t)Cin * Cout * 9 + Cout) * sizeof(float);
+}
+
+extern "C" int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const float* act_out, float slope, const float* w, float* dx, float* dW, float* db,
+                              int B, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(x && dy && w && dW && db && ws, UF_ERR_NULL, "uf_conv3x3_bwd: null pointer");
+    const bool wide_in = Cout <= 4 && !x_nchw && Cin % 4 == 0;
+    const bool wide_out = Cin <= 4 && x_nchw && (Cout == 16 || Cout == 32 || Cout == 64);
+    UF_REQUIRE(B > 0 && H > 0 && W > 1 && (wide_in || wide_out) && Cin * Cout * 9 <= CB_MAXW, UF_ERR_UNSUPPORTED,
+               "uf_conv3x3_bwd: Cin=%d Cout=%d nchw=%d: supported are (token rows, Cin %% 4 == 0, Cout <= 4) and (NCHW, Cin <= 4, Cout 16, 32 or 64)", Cin, Cout, x_nchw);
+    UF_REQUIRE(!act_out || wide_out, UF_ERR_UNSUPPORTED, "uf_conv3x3_bwd: the LeakyReLU mask is folded on the InputProj form only");
+    const size_t need = uf_conv3x3_bwd_workspace_bytes(B, H, W, Cin, Cout);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_conv3x3_bwd: workspace too small: %zu < %zu", ws_bytes, need);
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) {
+        const int grid = grid1d((long long)B * H * W * ((Cin + 3) / 4));
+        hipLaunchKernelGGL(conv3x3_dx_kernel, dim3(grid), dim3(256), 0, st, dy, act_out, slope, w, dx, B, H, W, Cin, Cout, x_nchw);
+        if (int rc = check_launch("conv3x3_dx")) return rc;
+    }
+    const int blocks = conv3x3_bwd_blocks(B, H), rpb = (B * H + blocks - 1) / blocks;
+    const int E = Cin * Cout * 9 + Cout;
+    int P = blocks;
+    float* part = (float*)ws;
+    if (wide_in) {
+        switch (Cout) {
+            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<1>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<2>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<3>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<4>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+        }
+    } else {
+        P = blocks * (64 / Cout);
+        switch (Cin) {
+            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<1>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<2>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<3>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<4>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+        }
+    }
+    if (int rc = check_launch("conv3x3_wgrad")) return rc;
+    const int nw = Cin * Cout * 9;
+    hipLaunchKernelGGL(column_sum_kernel, dim3((nw + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)part, P, (size_t)E, dW, nw);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((Cout + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)part + nw, P, (size_t)E, db, Cout);
+    return check_launch("conv3x3_wgrad_finalize");
 }

@@ -611,6 +611,25 @@ def rows_sum(x: Tensor) -> Tensor:
     return out
 
 
+def conv3x3_bwd(x: Tensor, dy_rows: Tensor, w: Tensor, B: int, H: int, W: int, nchw: bool = False, act_out: Optional[Tensor] = None, slope: float = 0.01,
+                need_dx: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+    """(dx, dW, db) of a 3x3 stride-1 pad-1 Conv2d with <= 4 channels on one side (InputProj / OutputProj): x = f32 token rows
+    (B*H*W, Cin) or the NCHW image when ``nchw``; dy_rows f32 (B*H*W, Cout); ``act_out``: the stored LeakyReLU output rows (InputProj)."""
+    _dev(x, dy_rows, w)
+    x, dy_rows, w = _c(x, torch.float32), _c(dy_rows, torch.float32), _c(w, torch.float32)
+    Cout, Cin = w.shape[0], w.shape[1]
+    act_out = None if act_out is None else _c(act_out, torch.float32)
+    dx = torch.empty_like(x) if need_dx else None
+    dW, db = torch.empty_like(w), torch.empty(Cout, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_conv3x3_bwd_workspace_bytes(B, H, W, Cin, Cout)
+    ws = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_conv3x3_bwd(_ptr(x), int(nchw), _ptr(dy_rows), _ptr(act_out), slope, _ptr(w), _ptr(dx), _ptr(dW), _ptr(db), B, H, W, Cin, Cout,
+                                      _ptr(ws), nbytes, _stream()), "uf_conv3x3_bwd")
+    return dx, dW, db
+
+
 def residual_combine(a: Optional[Tensor], b: Tensor, scale: Optional[Tensor], B: int, H: int, W: int, windowed: bool = False, shift: int = 0) -> Tensor:
     """f32 (B*H*W, C) = (a or 0) + scale[image] * b; b (bf16/f32 rows) is in WINDOW order when ``windowed`` (window_reverse + roll
     back folded in), ``scale`` = f32 (B,) DropPath scales or None."""

@@ -181,6 +181,20 @@ def _conv_backward(x_src: Tensor, nchw: bool, geom: Tuple[int, int, int, int], w
     return dx, dW, db[:Cout]
 
 
+def _conv3x3_backward(x: Tensor, nchw: bool, geom: Tuple[int, int, int, int], w: Tensor, dy_rows: Tensor, T: torch.dtype, act_out: Optional[Tensor] = None,
+                      need_dx: bool = True) -> Tuple[Optional[Tensor], Tensor, Tensor]:
+    """Backward of InputProj / OutputProj (3x3, stride 1, pad 1; LeakyReLU' folded in when ``act_out`` is given): the direct f32
+    kernels for the reference's shapes (embed_dim 16 / 32: a side of <= 4 channels), the patch-matrix route for anything else."""
+    B, H, W, Cin = geom
+    Cout = w.shape[0]
+    direct = (nchw and Cin <= 4 and Cout in (16, 32, 64)) or (not nchw and Cout <= 4 and Cin % 4 == 0)
+    if direct and Cin * Cout * 9 <= 2048:
+        return ops.conv3x3_bwd(x, dy_rows, w, B, H, W, nchw=nchw, act_out=act_out, slope=0.01, need_dx=need_dx)
+    if act_out is not None:
+        dy_rows = dy_rows * torch.where(act_out > 0, torch.ones_like(act_out), torch.full_like(act_out, 0.01))     # LeakyReLU(0.01), model.py:786
+    return _conv_backward(x, nchw, geom, w, dy_rows, 1, 1, T)
+
+
 class UformerTape:
     """One forward of the whole model (model.py:1269-1305) that keeps what the reverse sweep reads, and that sweep.
     ``drop_scales``: None (eval semantics) or a (2 * n_blocks, B) tensor of DropPath scales in execution order.
@@ -240,7 +254,7 @@ class UformerTape:
         return ops.output_proj(t, packing.pack_output_proj(sd["output_proj.proj.0.weight"]), sd["output_proj.proj.0.bias"], B, H, W,
                                img if cfg.dd_in == 3 else None)
 
-    def backward(self, dy: Tensor) -> Tuple[Tensor, Grads]:
+    def backward(self, dy: Tensor, need_dimg: bool = True) -> Tuple[Optional[Tensor], Grads]:
         from .spec import STAGES
         sd, cfg, T, B, H, res = self.sd, self.cfg, self.T, self.B, self.H, self.res
         g: Grads = {}
@@ -269,7 +283,7 @@ class UformerTape:
         dy = dy.float()
         dy_rows = dy.permute(0, 2, 3, 1).reshape(B * H * H, 3)
         C8 = self.head_in.shape[1]
-        d, g["output_proj.proj.0.weight"], g["output_proj.proj.0.bias"] = _conv_backward(self.head_in, False, (B, H, H, C8), sd["output_proj.proj.0.weight"], dy_rows, 1, 1, T)
+        d, g["output_proj.proj.0.weight"], g["output_proj.proj.0.bias"] = _conv3x3_backward(self.head_in, False, (B, H, H, C8), sd["output_proj.proj.0.weight"], dy_rows, T)
         done(["output_proj.proj.0.weight", "output_proj.proj.0.bias"])
         self.head_in = None
         dskip: List[Tensor] = [None] * 4
@@ -297,12 +311,11 @@ class UformerTape:
             done([f"dowsample_{s}.conv.0.weight", f"dowsample_{s}.conv.0.bias"])
             self.down_in[s] = self.skips[s] = None
             d = stage_bwd(s, dx, g)
-        so = self.stem_out
-        dpre = d * torch.where(so >= 0, torch.ones_like(so), torch.full_like(so, 0.01))     # LeakyReLU(0.01), model.py:786
-        dimg, g["input_proj.proj.0.weight"], g["input_proj.proj.0.bias"] = _conv_backward(self.img.float(), True, (B, H, H, self.img.shape[1]),
-                                                                                          sd["input_proj.proj.0.weight"], dpre, 1, 1, T)
+        # InputProj: LeakyReLU(0.01)' (model.py:786) from the sign of the stored output, folded into the conv backward
+        dimg, g["input_proj.proj.0.weight"], g["input_proj.proj.0.bias"] = _conv3x3_backward(self.img.float(), True, (B, H, H, self.img.shape[1]), sd["input_proj.proj.0.weight"], d, T,
+                                                                                             act_out=self.stem_out, need_dx=need_dimg)
         done(["input_proj.proj.0.weight", "input_proj.proj.0.bias"])
-        if cfg.dd_in == 3:
+        if need_dimg and cfg.dd_in == 3:
             dimg = dimg + dy                                                      # global residual, model.py:1305
         return dimg, g
 
@@ -333,7 +346,7 @@ class UformerFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dimg, g = ctx.tape.backward(dy.contiguous())
+        dimg, g = ctx.tape.backward(dy.contiguous(), need_dimg=ctx.img_needs_grad)
         ctx.tape = None                                                           # free the saved activations
         if ctx.sink is not None:      # the gradients already sit in the sink's buckets (= param.grad) and are being all-reduced
             grads = tuple(None for _ in ctx.names)
