@@ -253,6 +253,11 @@ int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const 
                             int n_mask, const void* dO, int ldo, void* dq, void* dk, void* dvt, float* dbias,
                             int n_windows, int heads, int head_dim, int H, int W, int shift, uf_dtype dtype,
                             void* ws, size_t ws_bytes, void* stream);
+/* the same backward with ONE output: dqkv T[n_windows*64][3C], the gradient of the fused q|k|v projection output in window-row
+ * order (heads merged; the q third already multiplied by head_dim^-0.5) -- the operand of the projection's weight / input gradients. */
+int uf_window_attention_bwd_qkv(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask,
+                                int n_mask, const void* dO, int ldo, void* dqkv, float* dbias, int n_windows, int heads,
+                                int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 /* depthwise 3x3 tap / bias gradients: dw9 f32[9][C] (tap-major, like w9), dbias f32[C], OVERWRITTEN;
  * h (the conv input) and dc (gradient of the conv output, before the bias): T[B][H][W][C], H multiple of 4 */
 size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);

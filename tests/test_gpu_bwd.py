@@ -324,7 +324,8 @@ def test_fused_training_gemm_epilogues_equal_the_two_pass_forms(dtype, M, N, K):
     assert torch.equal(pre, pre0) and torch.equal(act, ops.gelu(pre0))
     c = (torch.randn(M, N, generator=g(63)) * 2).to(dtype).cuda()
     zero = torch.zeros(N, device="cuda")
-    assert torch.equal(ops.linear_mul_dgelu(a, w, zero, c), ops.gelu_bwd(c, ops.linear(a, w, zero)))
+    two_pass = ops.gelu_bwd(c, ops.linear(a, w, zero))
+    assert rel(ops.linear_mul_dgelu(a, w, zero, c), two_pass.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -339,7 +340,9 @@ def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):
     pre, act = ops.dwconv3x3_pre_gelu(h, w9, bias)
     assert torch.equal(pre, pre0) and torch.equal(act, ops.gelu(pre0))
     flip = w9.flip(0).contiguous()
-    assert torch.equal(ops.dwconv3x3_mul_dgelu(h, flip, a), ops.gelu_bwd(a, ops.dwconv3x3(h, flip, None, gelu=False)))
+    # GELU' is inlined into a different instruction stream (fma contraction may differ by an ulp of the f32 product)
+    two_pass = ops.gelu_bwd(a, ops.dwconv3x3(h, flip, None, gelu=False))
+    assert rel(ops.dwconv3x3_mul_dgelu(h, flip, a), two_pass.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -355,10 +358,11 @@ def test_backward_streaming_helpers(dtype, shift):
     s = torch.tensor([0.0, 1.25, 1.25]).cuda()
     st = s.repeat_interleave(H * W).reshape(M, 1)
     ref = x + ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float() * st
-    assert torch.equal(ops.residual_combine(x, yw, s, B, H, W, windowed=True, shift=shift), ref)
+    same = (lambda a, b: torch.equal(a, b)) if dtype == torch.bfloat16 else (lambda a, b: rel(a, b.cpu()) < 1e-6)   # f32 b: the kernel's a + s*b is one fma
+    assert same(ops.residual_combine(x, yw, s, B, H, W, windowed=True, shift=shift), ref)
     assert torch.equal(ops.residual_combine(None, yw, None, B, H, W, windowed=True, shift=shift),
                        ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float())
-    assert torch.equal(ops.residual_combine(x, yw, s, B, H, W), x + yw.float() * st)
+    assert same(ops.residual_combine(x, yw, s, B, H, W), x + yw.float() * st)
     g1, g2 = torch.randn(M, C, generator=g(72)).cuda(), torch.randn(M, C, generator=g(73)).cuda()
     tot, out = ops.grad_fork(g1, g2, s, B, H, W, dtype, windowed=True, shift=shift, want_sum=True)
     assert torch.equal(tot, g1 + g2)
@@ -374,7 +378,7 @@ def test_backward_streaming_helpers(dtype, shift):
     assert torch.equal(ops.qkv_grad_merge(dq, dk, dvt, heads), ref)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout,nchw", [(2, 24, 40, 3, 32, True), (1, 16, 16, 3, 16, True), (3, 8, 20, 4, 64, True),
+@pytest.mark.parametrize("B,H,W,Cin,Cout,nchw", [(2, 24, 40, 3, 32, True), (1, 16, 16, 3, 16, True), (3, 8, 20, 4, 32, True), (1, 8, 12, 3, 64, True),
                                                   (2, 24, 40, 64, 3, False), (1, 16, 16, 32, 3, False), (5, 300, 12, 8, 4, False)])
 def test_conv3x3_bwd_direct_vs_torch_autograd(B, H, W, Cin, Cout, nchw):
     """uf_conv3x3_bwd (InputProj form with LeakyReLU' from the stored output, OutputProj form) against torch autograd on the CPU."""
@@ -398,3 +402,25 @@ def test_conv3x3_bwd_direct_vs_torch_autograd(B, H, W, Cin, Cout, nchw):
         dx, dW, db = ops.conv3x3_bwd(rows, dy_rows, w.detach().cuda(), B, H, W)
         ref_dx = x.grad.permute(0, 2, 3, 1).reshape(-1, Cin)
     assert rel(dx, ref_dx) < 2e-5 and rel(dW, w.grad) < 2e-5 and rel(db, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shift", [0, 4])
+def test_window_attention_bwd_merged_output(dtype, shift):
+    """uf_window_attention_bwd_qkv == uf_window_attention_bwd followed by the head merge (dq times head_dim^-0.5, scaled before the
+    one rounding to T instead of after a first one)."""
+    from uformer_amd import ops
+    B, H, heads, hd = 2, 16, 4, 32
+    C, nW = heads * hd, B * (H // 8) ** 2
+    M = nW * 64
+    q = (torch.randn(nW, heads, 64, hd, generator=g(90)) * hd ** -0.5).to(dtype).cuda()
+    k = torch.randn(nW, heads, 64, hd, generator=g(91)).to(dtype).cuda()
+    vt = torch.randn(nW, heads, hd, 64, generator=g(92)).to(dtype).cuda()
+    bias = (torch.randn(heads, 64, 64, generator=g(93)) * 0.5).cuda()
+    do = torch.randn(M, C, generator=g(94)).to(dtype).cuda()
+    dq, dk, dvt, dbias = ops.window_attention_bwd(q, k, vt, bias, do, H, H, shift)
+    dqkv, dbias2 = ops.window_attention_bwd_qkv(q, k, vt, bias, do, H, H, shift)
+    merge = lambda t: t.reshape(nW, heads, 64, hd).permute(0, 2, 1, 3).reshape(M, C)      # noqa: E731
+    assert torch.equal(dbias, dbias2)
+    assert torch.equal(dqkv[:, C:2 * C], merge(dk)) and torch.equal(dqkv[:, 2 * C:], merge(dvt.transpose(2, 3)))
+    assert rel(dqkv[:, :C], (merge(dq).float() * hd ** -0.5).cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "uf_linear_wgrad": (I, [P, I, P, I, P, P, I, I, I, I, P, c_size_t, P]),
     "uf_window_attention_bwd_workspace_bytes": (c_size_t, [I, I]),
     "uf_window_attention_bwd": (I, [P, P, P, P, P, I, P, I, P, P, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),
+    "uf_window_attention_bwd_qkv": (I, [P, P, P, P, P, I, P, I, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),
     "uf_dwconv3x3_wgrad_workspace_bytes": (c_size_t, [I, I]),
     "uf_dwconv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, c_size_t, P]),
     "uf_dwconv_linear2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),

@@ -14,9 +14,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // GELU'(a) = Phi(a) + a phi(a)   (nn.GELU default = erf form, model.py:657-660)
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float gelu_grad(float a) {
-    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
-}
+// (uf_common.h gelu_grad_t: the erf form for f32 operands, the derivative of the bf16 forward's own GELU for bf16 operands)
 
 template <typename T> struct Vec;
 template <> struct Vec<bf16> {
@@ -48,7 +46,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ a, 
     Vec<T>::load(a + i * N, fa);
     Vec<T>::load(dy + i * N, fd);
 #pragma unroll
-    for (int k = 0; k < N; ++k) fd[k] *= gelu_grad(fa[k]);
+    for (int k = 0; k < N; ++k) fd[k] *= gelu_grad_t<T>(fa[k]);
     Vec<T>::store(dx + i * N, fd);
 }
 
@@ -174,7 +172,9 @@ constexpr int LN_BWD_MAX_BLOCKS = 512;
 // written to partial[thread][10][N]; wgrad_finalize adds the threads that share a channel group.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DWB_R = 4;
-constexpr int DW_WGRAD_BLOCKS = 256;
+// workgroups of dwconv3x3_wgrad_kernel: 176 VGPRs = 2 workgroups per CU resident -> 512 fills the chip once (256 left every SIMD with
+// ONE wave of a memory-bound kernel); UF_DWWGRAD_BLOCKS overrides for A/B runs
+static int dw_wgrad_blocks() { static const int v = getenv("UF_DWWGRAD_BLOCKS") ? atoi(getenv("UF_DWWGRAD_BLOCKS")) : 0; return v > 0 ? v : 512; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ h, const T* __restrict__ dc, float* __restrict__ partial,
@@ -516,8 +516,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
                                                               const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
                                                               const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
-                                                              T* __restrict__ dvt, float* __restrict__ ws_bias, int n_windows, int heads,
-                                                              int H, int W, int shift) {
+                                                              T* __restrict__ dvt, T* __restrict__ dqkv, float qscale, float* __restrict__ ws_bias, int n_windows,
+                                                              int heads, int H, int W, int shift) {
     constexpr int HD = 32, SZ = sizeof(T), EP = 16 / SZ;
     constexpr int SD = HD * SZ + 16, ST = 64 * SZ + 16;       // row strides: [token][d] tiles, [d or token][token] tiles
     constexpr int PPT = 64 * HD / EP / 256;                   // 16-byte pieces per thread and tile (1 bf16, 2 f32)
@@ -652,14 +652,33 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
                 mma16(ov[c], a_gt, b_pt);      // D[row d][col j]
             }
         }
+        if (dqkv) {
+            // merged form: the gradient of the fused q|k|v projection output, T[n_windows*64][3C] in window-row order, channel
+            // h*32 + d of each third; dq is multiplied by the query scale here (it is the gradient wrt the SCALED query, model.py:497)
+            const int C3 = 3 * heads * HD;
+            T* row0 = dqkv + (size_t)bw * 64 * C3 + h * HD;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < 2; ++c) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                store1(dq + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, oq[c][r]);
-                store1(dk + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, ok[c][r]);
-                store1(dvt + base + (16 * c + 4 * fg + r) * 64 + i0 + fr, ov[c][r]);
+                for (int r = 0; r < 4; ++r) {
+                    store1(row0 + (size_t)(i0 + 4 * fg + r) * C3 + 16 * c + fr, oq[c][r] * qscale);
+                    store1(row0 + (size_t)(i0 + 4 * fg + r) * C3 + heads * HD + 16 * c + fr, ok[c][r]);
+                }
+                // dv^T tile: lane holds d = 16c + 4fg + 0..3 of key token i0 + fr: four consecutive channels of one row
+                T* dst = row0 + (size_t)(i0 + fr) * C3 + 2 * heads * HD + 16 * c + 4 * fg;
+                if constexpr (SZ == 2) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2bf(ov[c][0], ov[c][1]), pack2bf(ov[c][2], ov[c][3])};
+                else *reinterpret_cast<f32x4*>(dst) = ov[c];
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    store1(dq + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, oq[c][r]);
+                    store1(dk + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, ok[c][r]);
+                    store1(dvt + base + (16 * c + 4 * fg + r) * 64 + i0 + fr, ov[c][r]);
+                }
+        }
         __syncthreads();   // the next window overwrites the tiles
     }
     float* wb = ws_bias + ((size_t)blockIdx.y * heads + h) * 4096;
@@ -749,7 +768,7 @@ extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {
     const int N = dtype == UF_BF16 ? 8 : 4;
     if (C <= 0 || C % N) return 0;
     const int cv = C / N;
-    int blocks = DW_WGRAD_BLOCKS;
+    int blocks = dw_wgrad_blocks();
     while (((long long)blocks * 256) % cv) ++blocks;   // stride must be a multiple of the channel-group count
     return (size_t)blocks * 256 * 10 * N * sizeof(float);
 }
@@ -839,10 +858,10 @@ extern "C" size_t uf_window_attention_bwd_workspace_bytes(int n_windows, int hea
     return (size_t)attn_bwd_chunks(n_windows, heads) * heads * 4096 * sizeof(float);
 }
 
-extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask, int n_mask,
-                                       const void* dO, int ldo, void* dq, void* dk, void* dvt, float* dbias, int n_windows, int heads,
-                                       int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
-    UF_REQUIRE(q && k && vt && bias_dense && dO && dq && dk && dvt && dbias && ws, UF_ERR_NULL, "uf_window_attention_bwd: null pointer");
+static int window_attention_bwd_any(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask, int n_mask,
+                                    const void* dO, int ldo, void* dq, void* dk, void* dvt, void* dqkv, float* dbias, int n_windows, int heads,
+                                    int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(q && k && vt && bias_dense && dO && ((dq && dk && dvt) || dqkv) && dbias && ws, UF_ERR_NULL, "uf_window_attention_bwd: null pointer");
     UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: dtype %d", (int)dtype);
     UF_REQUIRE(n_windows > 0 && heads > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: n_windows=%d heads=%d", n_windows, heads);
     UF_REQUIRE(head_dim == 32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: head_dim %d (32 only so far)", head_dim);
@@ -856,6 +875,7 @@ extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void*
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_window_attention_bwd: workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const int G = attn_bwd_chunks(n_windows, heads);
+    const float qscale = (float)(1.0 / sqrt((double)head_dim));   // python: head_dim ** -0.5, rounded once to f32
     const int SZ = (int)dtype_size(dtype);
     const int smem = 4 * 64 * (32 * SZ + 16) + 3 * 32 * (64 * SZ + 16) + 4 * 64 * (64 * SZ + 16);
     char name[96] = "";
@@ -867,12 +887,12 @@ extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void*
             static bool done[64] = {};
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16>), smem, done, "window_attn_bwd")) return rc;
             hipLaunchKernelGGL(window_attn_bwd_kernel<bf16>, dim3(heads, G), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                               bias_dense, mask, n_mask, (const bf16*)dO, ldo, (bf16*)dq, (bf16*)dk, (bf16*)dvt, (float*)ws, n_windows, heads, H, W, shift);
+                               bias_dense, mask, n_mask, (const bf16*)dO, ldo, (bf16*)dq, (bf16*)dk, (bf16*)dvt, (bf16*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
         } else {
             static bool done[64] = {};
             if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<float>), smem, done, "window_attn_bwd")) return rc;
             hipLaunchKernelGGL(window_attn_bwd_kernel<float>, dim3(heads, G), dim3(256), smem, st, (const float*)q, (const float*)k, (const float*)vt,
-                               bias_dense, mask, n_mask, (const float*)dO, ldo, (float*)dq, (float*)dk, (float*)dvt, (float*)ws, n_windows, heads, H, W, shift);
+                               bias_dense, mask, n_mask, (const float*)dO, ldo, (float*)dq, (float*)dk, (float*)dvt, (float*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
         }
     }
     int rc = check_launch("window_attn_bwd");
@@ -880,6 +900,22 @@ extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void*
     const int nb = heads * 4096;
     hipLaunchKernelGGL(column_sum_kernel, dim3((nb + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)ws, G, (size_t)nb, dbias, nb);
     return check_launch("window_attn_bwd_finalize");
+}
+
+extern "C" int uf_window_attention_bwd(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask, int n_mask,
+                                       const void* dO, int ldo, void* dq, void* dk, void* dvt, float* dbias, int n_windows, int heads,
+                                       int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(dq && dk && dvt, UF_ERR_NULL, "uf_window_attention_bwd: null output");
+    return window_attention_bwd_any(q, k, vt, bias_dense, mask, n_mask, dO, ldo, dq, dk, dvt, nullptr, dbias, n_windows, heads, head_dim, H, W, shift, dtype, ws, ws_bytes, stream);
+}
+
+// the same backward writing ONE tensor: dqkv T[n_windows*64][3C], the gradient of the fused q|k|v projection output (heads merged,
+// dq times head_dim^-0.5) -- what uf_linear_wgrad / the input-gradient GEMM of the projection read next.
+extern "C" int uf_window_attention_bwd_qkv(const void* q, const void* k, const void* vt, const float* bias_dense, const float* mask, int n_mask,
+                                           const void* dO, int ldo, void* dqkv, float* dbias, int n_windows, int heads, int head_dim, int H, int W,
+                                           int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(dqkv && ((uintptr_t)dqkv % 16) == 0, UF_ERR_NULL, "uf_window_attention_bwd_qkv: dqkv must be a 16-byte aligned pointer");
+    return window_attention_bwd_any(q, k, vt, bias_dense, mask, n_mask, dO, ldo, nullptr, nullptr, nullptr, dqkv, dbias, n_windows, heads, head_dim, H, W, shift, dtype, ws, ws_bytes, stream);
 }
 
 // ===============================================================================================================================

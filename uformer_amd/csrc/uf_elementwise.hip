@@ -121,9 +121,6 @@ template <typename T, int N> __device__ __forceinline__ void round_to(float* f) 
         }
     }
 }
-__device__ __forceinline__ float dw_gelu_grad(float a) {   // GELU'(a), the expression of uf_gelu_bwd
-    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
-}
 
 // ACT 0: the bare stencil (also the backward: flipped taps);  1: + GELU (the LeFF forward);  2: out = pre-activation AND aux = GELU of
 // it as stored (training forward keeps both);  3: out = stencil (as stored) * GELU'(aux) (input gradient through the preceding GELU)
@@ -145,9 +142,14 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
 #pragma unroll
     for (int r = 0; r < DW_R; ++r)
 #pragma unroll
-        for (int i = 0; i < N; ++i) acc[r][i] = bias ? bias[c + i] : 0.0f;
+        for (int i = 0; i < N; i += 4) {    // 16-byte loads (C % 4 == 0): as dword loads the per-lane 32-byte stride made every tap-weight load touch 16 cache lines,
+            const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c + i) : f32x4{0.f, 0.f, 0.f, 0.f};   // 80 such loads per thread against 18 data loads
+            acc[r][i] = bv[0]; acc[r][i + 1] = bv[1]; acc[r][i + 2] = bv[2]; acc[r][i + 3] = bv[3];
+        }
     const T* xb = x + (size_t)b * H * W * C + c;
-#pragma unroll
+    // one column tap at a time (not unrolled): fully unrolled, hipcc hoists all 18 loads and 72 tap weights, 208-234 VGPRs = 2
+    // waves per SIMD, and the kernel ran at 2 TB/s; with 6 loads in flight per thread it fits 4-5 waves
+#pragma unroll 1
     for (int kx = 0; kx < 3; ++kx) {
         // zero padding without guarded loads (a guarded load costs an exec-masked branch and a
         // vmcnt(0) wait): coordinates are clamped and the column / row masks are folded into the
@@ -159,7 +161,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int i = 0; i < N; ++i) wk[ky][i] = w9[(ky * 3 + kx) * C + c + i] * mx;
+            for (int i = 0; i < N; i += 4) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w9 + (size_t)(ky * 3 + kx) * C + c + i);
+                wk[ky][i] = wv[0] * mx; wk[ky][i + 1] = wv[1] * mx; wk[ky][i + 2] = wv[2] * mx; wk[ky][i + 3] = wv[3] * mx;
+            }
 #pragma unroll
         for (int r = -1; r <= DW_R; ++r) {   // input row y0 + r feeds output rows r+1-ky
             const int iyr = y0 + r;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
             Vec16<T>::load(aux + o, a);
             round_to<T, N>(acc[r]);
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc[r][i] *= dw_gelu_grad(a[i]);
+            for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
         }
         Vec16<T>::store(out + o, acc[r]);
         if constexpr (ACT == 2) {
@@ -466,6 +471,7 @@ int dwconv_any(const char* fn, const void* x, const float* w9, const float* bias
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "%s: bad shape (H must be a multiple of %d)", fn, DW_R);
     UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
     UF_REQUIRE(C % (dtype == UF_BF16 ? 8 : 4) == 0, UF_ERR_SHAPE, "%s: C=%d must be a multiple of %d", fn, C, dtype == UF_BF16 ? 8 : 4);
+    UF_REQUIRE(((uintptr_t)w9 % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0), UF_ERR_ALIGN, "%s: w9 / bias must be 16-byte aligned", fn);
     hipStream_t st = (hipStream_t)stream;
     char tname[64] = "";
     if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3_m%d %dx%d", mode, B * H * W, C);

@@ -87,10 +87,6 @@ template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* f
     if constexpr (sizeof(T) == 2) return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
     else return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
-// GELU'(a) = Phi(a) + a phi(a)   (nn.GELU erf form; the same expression as uf_gelu_bwd)
-__device__ __forceinline__ float gelu_grad(float a) {
-    return 0.5f * (1.0f + erff(a * 0.70710678118654752440f)) + a * __expf(-0.5f * a * a) * 0.39894228040143267794f;
-}
 
 template <typename T, int EP>
 __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x4 acc) {
@@ -274,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                         unpack_chunk<T>(val, f);
                         unpack_chunk<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldo + n), a);
 #pragma unroll
-                        for (int e = 0; e < EPC; ++e) f[e] *= gelu_grad(a[e]);
+                        for (int e = 0; e < EPC; ++e) f[e] *= gelu_grad_t<T>(a[e]);
                         *reinterpret_cast<u32x4*>(dst) = pack_chunk<T>(f);
                     } else
                     *reinterpret_cast<u32x4*>(dst) = val;

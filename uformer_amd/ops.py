@@ -373,6 +373,28 @@ def window_attention_bwd(q: Tensor, k: Tensor, vt: Tensor, bias: Tensor, do: Ten
     return dq, dk, dvt, dbias
 
 
+def window_attention_bwd_qkv(q: Tensor, k: Tensor, vt: Tensor, bias: Tensor, do: Tensor, H: int, W: int, shift: int = 0,
+                             mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """window_attention_bwd writing the merged gradient of the q|k|v projection output: (dqkv (nW*64, 3C), dbias (heads,64,64))."""
+    _dev(q, k, vt, bias, do)
+    dt = uf_dtype(q.dtype)
+    q, k, vt, do = _c(q), _c(k, q.dtype), _c(vt, q.dtype), _c(do, q.dtype)
+    heads = bias.shape[0]
+    hd = q.shape[-1]
+    n_windows = q.numel() // (heads * 64 * hd)
+    dqkv = torch.empty(n_windows * 64, 3 * heads * hd, dtype=q.dtype, device=q.device)
+    dbias = torch.empty(heads, 64, 64, dtype=torch.float32, device=q.device)
+    m = _c(mask, torch.float32) if mask is not None else None
+    lib = _lib.load()
+    nbytes = lib.uf_window_attention_bwd_workspace_bytes(n_windows, heads)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.uf_window_attention_bwd_qkv(_ptr(q), _ptr(k), _ptr(vt), _ptr(_c(bias, torch.float32)), _ptr(m) if m is not None else None,
+                                                   m.shape[0] if m is not None else 0, _ptr(do), do.shape[-1], _ptr(dqkv), _ptr(dbias), n_windows, heads, hd,
+                                                   H, W, shift, dt, _ptr(ws), nbytes, _stream()), "uf_window_attention_bwd_qkv")
+    return dqkv, dbias
+
+
 def dwconv3x3_wgrad(h: Tensor, dc: Tensor):
     """Tap (9,C) and bias (C,) gradients of the depthwise 3x3 from its input h and output gradient dc, both T(B,H,W,C)."""
     _dev(h, dc)

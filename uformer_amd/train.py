@@ -128,10 +128,9 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
     g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = ops.linear_wgrad(dyw, sv["o"])
     do = _input_grad(dyw, pk.wp_t)
-    dq, dk, dvt, dbias = ops.window_attention_bwd(sv["q"], sv["k"], sv["vt"], pk.bias, do, H, W, shift)
+    dqkv, dbias = ops.window_attention_bwd_qkv(sv["q"], sv["k"], sv["vt"], pk.bias, do, H, W, shift)    # heads merged, dq times the query scale
     g[prefix + "attn.relative_position_bias_table"] = ops.rpb_table_grad(dbias)       # gather over the pairs of each table entry: deterministic
     nW = M // 64
-    dqkv = ops.qkv_grad_merge(dq, dk, dvt, heads)                                     # head merge + the query scale
     dWqkv, dbqkv = ops.linear_wgrad(dqkv, sv["xn"])
     g[prefix + "attn.qkv.to_q.weight"], g[prefix + "attn.qkv.to_kv.weight"] = dWqkv[:C], dWqkv[C:]
     g[prefix + "attn.qkv.to_q.bias"], g[prefix + "attn.qkv.to_kv.bias"] = dbqkv[:C], dbqkv[C:]
