@@ -75,7 +75,7 @@ def bench_stamps():
     """Phase timestamps of attn_block (cycle counter of wave 0..N of every 64th window)."""
     from uformer_amd import _lib, model
     lib = _lib.load()
-    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 64, 128, 4)):
+    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 64, 128, 4), (16, 128, 128, 4), (16, 32, 256, 8)):
         blk = model.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
         bp = blk._pack(torch.bfloat16)
         M = B * H * H
@@ -83,13 +83,13 @@ def bench_stamps():
         nbytes = lib.uf_block_workspace_bytes(M, C, 1)
         ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
         st = torch.cuda.current_stream().cuda_stream
-        waves = 8 if C == 512 else 4
+        waves = 8 if (C == 512 or (C == 256 and M // 64 <= 256)) else 4
         tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
         for _ in range(3):
-            lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+            lib.uf_lewin_block_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(tb.data_ptr())
-        lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+        lib.uf_lewin_block_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
         torch.cuda.synchronize()
         lib.uf_debug_set_tbuf(None)
         t = tb[:65536].cpu().reshape(-1, waves, 16)
@@ -98,7 +98,7 @@ def bench_stamps():
         for bi in range(min(t.shape[0], 6)):
             row = t[bi, 0]
             print(f"  block {bi * 64:5d}: start {int(row[0] - t0):8d} | LN {int(row[1] - row[0]):7d} bar {int(row[2] - row[1]):6d} QKV {int(row[3] - row[2]):7d} "
-                  f"[pack+S {int(row[8] - row[3]):6d} softmax {int(row[9] - row[8]):6d} PV {int(row[10] - row[9]):6d} store {int(row[4] - row[10]):6d}] rest-units {int(row[5] - row[4]):7d} bar {int(row[6] - row[5]):6d} proj {int(row[7] - row[6]):7d}")
+                  f"[pack+S {int(row[8] - row[3]):6d} softmax {int(row[9] - row[8]):6d} PV {int(row[10] - row[9]):6d} store {int(row[4] - row[10]):6d}] rest-units {int(row[5] - row[4]):7d} bar {int(row[6] - row[5]):6d} proj {int(row[7] - row[6]):7d} resid+LN2 {int(row[11] - row[7]):6d} fc1 {int(row[12] - row[11]):7d} | total {int(row[12] - row[0]):7d}")
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "stamps":

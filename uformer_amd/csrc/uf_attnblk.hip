@@ -620,7 +620,9 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     if constexpr (SZ == 2) {
         if (p.h1) {
             lds_barrier();
+            stamp(11);
             fc1_units<T, C, WAVES>(Xn, SA, reinterpret_cast<const T*>(p.W1), p.b1, reinterpret_cast<T*>(p.h1), geo, wave, lane);
+            stamp(12);
         }
     }
     census.end(p.tbuf, bw);
