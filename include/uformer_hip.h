@@ -306,6 +306,64 @@ int uf_grad_fork(const float* g1, const float* g2, float* sum_out, void* cast_ou
 int uf_qkv_grad_merge(const void* dq, const void* dk, const void* dvt, void* dqkv, int n_windows, int heads, int head_dim,
                       uf_dtype dtype, void* stream);
 
+/* ---- a15: block-level backward = recomputation + gradients (SURVEY 8(b) export list) --------------------------------------------
+ * The training forward (uf_lewin_block_train_fwd) keeps only a block's f32 INPUT; these entry points rebuild the intermediates
+ * from it with the op-level forward kernels and differentiate them (csrc/uf_trainblk.hip: host composition, every launch on the
+ * caller's stream, all temporaries in the caller's workspace).  Operands as a training step packs them per step: */
+typedef struct uf_block_train_params {
+    const float* norm1_w;  const float* norm1_b;  const float* norm2_w;  const float* norm2_b;   /* (C) each */
+    const float* modulator;      /* (64,C) or NULL */
+    const float* rpb_dense;      /* (heads,64,64) = relative_position_bias_table[relative_position_index] */
+    const void* wqkv;            /* T (3C,C) row-major: cat(attn.qkv.to_q.weight, attn.qkv.to_kv.weight) */
+    const void* wqkv_t;          /* T (C,3C): its transpose (input-gradient GEMM) */
+    const float* bqkv;           /* (3C) */
+    const void* wproj;  const void* wproj_t;  const float* bproj;      /* T (C,C), transpose, (C) */
+    const void* w1;     const void* w1_t;     const float* b1;         /* T (4C,C), T (C,4C), (4C) */
+    const float* wdw9;  const float* wdw9_flip;  const float* bdw;     /* (9,4C) taps, the same with the tap axis reversed, (4C) */
+    const void* w2_t;            /* T (4C,C): mlp.linear2.0.weight transposed */
+    int32_t shift, heads;
+} uf_block_train_params;
+/* f32 outputs, OVERWRITTEN, in the layouts of the reference's parameters */
+typedef struct uf_block_grads {
+    float* norm1_w;  float* norm1_b;  float* norm2_w;  float* norm2_b;
+    float* modulator;            /* (64,C); NULL iff the block has no modulator */
+    float* rpb_table;            /* (225, heads) attn.relative_position_bias_table */
+    float* wqkv;  float* bqkv;   /* (3C,C), (3C): rows [0,C) = to_q, [C,3C) = to_kv */
+    float* wproj; float* bproj;
+    float* w1;    float* b1;
+    float* wdw;   float* bdw;    /* (4C,1,3,3), (4C) */
+    float* w2;    float* b2;     /* (C,4C), (C) */
+} uf_block_grads;
+size_t uf_lewin_block_bwd_workspace_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype);   /* serves all three below */
+/* x: the block input f32[B*H*W][C]; dy: gradient of the block output; dx: gradient of the input (may NOT alias); drop_*: the
+ * per-image DropPath scales the forward used (f32[B]) or NULL.  model.py:951-987. */
+int uf_lewin_block_bwd(const uf_block_train_params* p, const float* x, const float* dy, float* dx, const float* drop_attn,
+                       const float* drop_leff, const uf_block_grads* g, int B, int H, int W, int C, uf_dtype dtype,
+                       void* ws, size_t ws_bytes, void* stream);
+/* the halves: y = x1 + DropPath(LeFF(LN2(x1))) given x1 and dy -> dx1 (g: norm2, w1, b1, wdw, bdw, w2, b2 written);
+ * x1 = x + DropPath(attention branch) given x and dx1 -> dx (g: norm1, modulator, rpb_table, wqkv, bqkv, wproj, bproj written). */
+int uf_leff_bwd(const uf_block_train_params* p, const float* x1, const float* dy, float* dx1, const float* drop_leff,
+                const uf_block_grads* g, int B, int H, int W, int C, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+int uf_lewin_attn_bwd(const uf_block_train_params* p, const float* x, const float* dx1, float* dx, const float* drop_attn,
+                      const uf_block_grads* g, int B, int H, int W, int C, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* Downsample backward (Conv2d k4 s2 p1 on token rows, model.py:728-746): x f32[B*H*W][ld_x] the layer input, dy f32[B*H/2*W/2][Cout],
+ * w_pk_t T[16 Cin][Cout] = transpose of the forward's packed weight (k = (ky*4+kx)*Cin + c).  dx f32 rows of stride ld_dx
+ * (accumulate = 1: added to what is there, e.g. the skip connection's gradient); dW_pk f32[Cout][16 Cin] in the PACKED order
+ * (reference layout = reshape (Cout,4,4,Cin) -> permute (0,3,1,2)); db f32[Cout]. */
+size_t uf_downsample_bwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, uf_dtype dtype);
+int uf_downsample_bwd(const float* x, int ld_x, const float* dy, const void* w_pk_t, float* dx, int ld_dx, int accumulate,
+                      float* dW_pk, float* db, int B, int H, int W, int Cin, int Cout, uf_dtype dtype, void* ws,
+                      size_t ws_bytes, void* stream);
+/* Upsample backward (ConvTranspose2d k2 s2 into the first Cout channels of the concat buffer, model.py:749-771, :1288):
+ * d f32[B*2H*2W][ld_d] gradient of the concat buffer (columns [0,Cout) are read; the skip half is columns [Cout, ld_d));
+ * x f32[B*H*W][Cin] the layer input (dense rows); w_pk_t T[Cin][4 Cout] = transpose of the forward's packed weight
+ * (n = (dy*2+dx)*Cout + co).  dx f32[B*H*W][Cin]; dW_pk f32[4 Cout][Cin] packed order (reference layout (Cin,Cout,2,2) =
+ * reshape (2,2,Cout,Cin) -> permute (3,2,0,1)); db f32[Cout]. */
+size_t uf_upsample_cat_bwd_workspace_bytes(int B, int H, int W, int Cin, int Cout, uf_dtype dtype);
+int uf_upsample_cat_bwd(const float* d, int ld_d, const float* x, int ld_x, const void* w_pk_t, float* dx, float* dW_pk,
+                        float* db, int B, int H, int W, int Cin, int Cout, uf_dtype dtype, void* ws, size_t ws_bytes,
+                        void* stream);
+
 /* ---- f-2: training-step tail ------------------------------------------------------------------------------
  * CharbonnierLoss.forward + its gradient in one pass (losses.py:41-52; criterion of train/train_denoise.py:164,181):
  *   loss[0] = mean(sqrt((y - target)^2 + eps^2));   dy[i] = grad_scale * (y - target)[i] / sqrt(.) / n   (dy may be NULL)

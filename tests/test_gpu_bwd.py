@@ -424,3 +424,34 @@ def test_window_attention_bwd_merged_output(dtype, shift):
     assert torch.equal(dbias, dbias2)
     assert torch.equal(dqkv[:, C:2 * C], merge(dk)) and torch.equal(dqkv[:, 2 * C:], merge(dvt.transpose(2, 3)))
     assert rel(dqkv[:, :C], (merge(dq).float() * hd ** -0.5).cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_block_level_backward_entry_points(dtype):
+    """uf_lewin_block_bwd (recomputation + backward in one C call) == uf_leff_bwd after uf_lewin_attn_bwd on the same operands == the
+    op-by-op tape of uformer_amd/train.py (same kernels, same order: identical bits), with DropPath scales and a modulator."""
+    from uformer_amd import ops, spec, train
+    B, H, C, heads, shift = 3, 16, 64, 2, 4
+    cfg = spec.arch_config("tiny32", 128)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 11).items()}
+    prefix = "decoderlayer_3.blocks.0."                                       # C = 64, 2 heads, modulator
+    assert sd[prefix + "norm1.weight"].numel() == C and (prefix + "modulator.weight") in sd
+    pk = train.BlockPack(sd, prefix, heads, shift, dtype, fused=False)
+    x = torch.randn(B * H * H, C, generator=g(100)).cuda()
+    dy = torch.randn(B * H * H, C, generator=g(101)).cuda()
+    drop = torch.tensor([[1.25, 0.0, 1.25], [0.0, 1.25, 1.25]]).cuda()
+    y, sv = train.lewin_block_forward(x.reshape(B, H * H, C), sd, prefix, heads, shift, dtype, drop, pk)
+    dx_ref, g_ref = train.lewin_block_backward(sv, dy.reshape(B, H * H, C))
+    dx, gv = ops.lewin_block_bwd(pk.train_params, x, dy, drop[0], drop[1], B, H, H, heads, dtype)
+    named = train._named_block_grads(prefix, gv, C)
+    assert torch.equal(dx, dx_ref.reshape(-1, C))
+    assert set(named) == set(g_ref)
+    for k in g_ref:
+        assert torch.equal(named[k].reshape(g_ref[k].shape), g_ref[k]), k
+    dx1, g_l = ops.lewin_block_bwd(pk.train_params, sv["x1"], dy, None, drop[1], B, H, H, heads, dtype, half="leff")
+    dx2, g_a = ops.lewin_block_bwd(pk.train_params, x, dx1, drop[0], None, B, H, H, heads, dtype, half="attn")
+    assert torch.equal(dx2, dx)
+    for k in ("norm2_w", "norm2_b", "w1", "b1", "wdw", "bdw", "w2", "b2"):
+        assert torch.equal(g_l[k], gv[k]), k
+    for k in ("norm1_w", "norm1_b", "modulator", "rpb_table", "wqkv", "bqkv", "wproj", "bproj"):
+        assert torch.equal(g_a[k], gv[k]), k

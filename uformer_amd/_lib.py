@@ -26,6 +26,19 @@ class BlockParams(C.Structure):
         ("shift", C.c_int32), ("heads", C.c_int32)]
 
 
+class BlockTrainParams(C.Structure):
+    """``uf_block_train_params`` (include/uformer_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b", "modulator", "rpb_dense", "wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj",
+        "w1", "w1_t", "b1", "wdw9", "wdw9_flip", "bdw", "w2_t")] + [("shift", C.c_int32), ("heads", C.c_int32)]
+
+
+class BlockGrads(C.Structure):
+    """``uf_block_grads`` (include/uformer_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b", "modulator", "rpb_table", "wqkv", "bqkv", "wproj", "bproj", "w1", "b1", "wdw", "bdw", "w2", "b2")]
+
+
 class ModelDesc(C.Structure):
     """``uf_model_desc`` (include/uformer_hip.h)."""
     _fields_ = [
@@ -90,6 +103,14 @@ SIGNATURES = {
     "uf_rpb_table_grad": (I, [P, P, I, P]),
     "uf_im2col": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "uf_col2im": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "uf_lewin_block_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I, I]),
+    "uf_lewin_block_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
+    "uf_leff_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
+    "uf_lewin_attn_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
+    "uf_downsample_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I, I]),
+    "uf_downsample_bwd": (I, [P, I, P, P, P, I, I, P, P, I, I, I, I, I, I, P, C.c_size_t, P]),
+    "uf_upsample_cat_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I, I]),
+    "uf_upsample_cat_bwd": (I, [P, I, P, I, P, P, P, P, I, I, I, I, I, I, P, C.c_size_t, P]),
     "uf_conv3x3_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I]),
     "uf_conv3x3_bwd": (I, [P, I, P, P, C.c_float, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
     "uf_residual_combine": (I, [P, P, I, P, P, I, I, I, I, I, I, I, P]),

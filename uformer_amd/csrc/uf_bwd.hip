@@ -1083,7 +1083,7 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float*
 // out[tok] = (a ? a[tok] : 0) + s(tok) * b[row],  row = the window-order index of tok when `windowed` (b is in window order: this
 // is window_reverse + roll back, model.py:975-980), else tok;  s = scale[image of tok] or 1.
 template <typename TB>
-__global__ __launch_bounds__(256) void residual_combine_kernel(const float* __restrict__ a, const TB* __restrict__ b, float* __restrict__ out, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void residual_combine_kernel(const float* a /* may alias out (in place) */, const TB* __restrict__ b, float* out, const float* __restrict__ scale,
                                                                int B, int H, int W, int C, int windowed, int shift) {
     const int cv = C / 8;
     const long long total = (long long)B * H * W * cv;
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(256) void residual_combine_kernel(const float* __re
 // t = g1[tok] (+ g2[tok]);  sum_out[tok] = t (optional);  cast_out[row] = T(t * s(tok)),  row = window-order index of tok when
 // `windowed` (roll + window_partition, model.py:957-963), else tok.
 template <typename TO>
-__global__ __launch_bounds__(256) void grad_fork_kernel(const float* __restrict__ g1, const float* __restrict__ g2, float* __restrict__ sum_out, TO* __restrict__ cast_out,
+__global__ __launch_bounds__(256) void grad_fork_kernel(const float* g1 /* may alias sum_out (in place) */, const float* __restrict__ g2, float* sum_out, TO* __restrict__ cast_out,
                                                         const float* __restrict__ scale, int B, int H, int W, int C, int windowed, int shift) {
     const int cv = C / 8;
     const long long total = (long long)B * H * W * cv;

@@ -486,6 +486,11 @@ def output_proj(x: Tensor, w: Tensor, bias: Tensor, B: int, H: int, W: int, img:
 # ---------------------------------------------------------------------------------------
 # training-step tail, metrics, arbitrary-resolution wrapper, input pipeline
 # ---------------------------------------------------------------------------------------
+def _byref(struct):
+    import ctypes
+    return ctypes.byref(struct)
+
+
 def _ws(nbytes: int, device) -> Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
@@ -631,6 +636,103 @@ def rows_sum(x: Tensor) -> Tensor:
     with torch.cuda.device(x.device):
         _lib.check(lib.uf_rows_sum(_ptr(x), N, _ptr(out), M, N, dt, _ptr(ws), nbytes, _stream()), "uf_rows_sum")
     return out
+
+
+def lewin_block_bwd_workspace_bytes(B: int, H: int, W: int, C: int, heads: int, dtype) -> int:
+    return int(_lib.load().uf_lewin_block_bwd_workspace_bytes(B, H, W, C, heads, uf_dtype(dtype)))
+
+
+def _block_grads(C: int, heads: int, modulator: bool, device):
+    """One flat f32 buffer holding all parameter gradients of a block, its uf_block_grads view and {field: tensor view}."""
+    shapes = [("norm1_w", (C,)), ("norm1_b", (C,)), ("norm2_w", (C,)), ("norm2_b", (C,)), ("modulator", (64, C) if modulator else None),
+              ("rpb_table", (225, heads)), ("wqkv", (3 * C, C)), ("bqkv", (3 * C,)), ("wproj", (C, C)), ("bproj", (C,)), ("w1", (4 * C, C)), ("b1", (4 * C,)),
+              ("wdw", (4 * C, 1, 3, 3)), ("bdw", (4 * C,)), ("w2", (C, 4 * C)), ("b2", (C,))]
+    total = 0
+    offs = {}
+    for name, shp in shapes:
+        if shp is None:
+            continue
+        n = 1
+        for d in shp:
+            n *= d
+        offs[name] = (total, n, shp)
+        total += (n + 63) // 64 * 64                          # 256-byte aligned pieces
+    flat = torch.empty(total, dtype=torch.float32, device=device)
+    views = {name: flat[o:o + n].view(shp) for name, (o, n, shp) in offs.items()}
+    g = _lib.BlockGrads()
+    for name, _ in shapes:
+        setattr(g, name, views[name].data_ptr() if name in views else None)
+    return flat, g, views
+
+
+def lewin_block_bwd(tp, x: Tensor, dy: Tensor, drop_attn: Optional[Tensor], drop_leff: Optional[Tensor], B: int, H: int, W: int, heads: int, dtype,
+                    ws: Optional[Tensor] = None, half: str = "block"):
+    """Recomputation + backward of one LeWin block through uf_lewin_block_bwd (``half``: "block", or "leff" / "attn" for the two
+    halves: x is then x1 resp. the block input and dy the gradient of that half's output).  tp: _lib.BlockTrainParams.
+    Returns (dx f32 (B*H*W, C), {uf_block_grads field: f32 gradient tensor})."""
+    _dev(x, dy)
+    x, dy = _c(x, torch.float32), _c(dy, torch.float32)
+    C = x.shape[-1]
+    lib = _lib.load()
+    dt = uf_dtype(dtype)
+    nbytes = lib.uf_lewin_block_bwd_workspace_bytes(B, H, W, C, heads, dt)
+    if ws is None or ws.numel() < nbytes:
+        ws = _ws(nbytes, x.device)
+    _flat, g, views = _block_grads(C, heads, bool(tp.modulator), x.device)
+    dx = torch.empty_like(x)
+    da = None if drop_attn is None else _c(drop_attn, torch.float32)
+    dl = None if drop_leff is None else _c(drop_leff, torch.float32)
+    with torch.cuda.device(x.device):
+        if half == "block":
+            rc = lib.uf_lewin_block_bwd(_byref(tp), _ptr(x), _ptr(dy), _ptr(dx), _ptr(da), _ptr(dl), _byref(g), B, H, W, C, dt, _ptr(ws), ws.numel(), _stream())
+        elif half == "leff":
+            rc = lib.uf_leff_bwd(_byref(tp), _ptr(x), _ptr(dy), _ptr(dx), _ptr(dl), _byref(g), B, H, W, C, dt, _ptr(ws), ws.numel(), _stream())
+        else:
+            rc = lib.uf_lewin_attn_bwd(_byref(tp), _ptr(x), _ptr(dy), _ptr(dx), _ptr(da), _byref(g), B, H, W, C, dt, _ptr(ws), ws.numel(), _stream())
+        _lib.check(rc, "uf_lewin_block_bwd" if half == "block" else ("uf_leff_bwd" if half == "leff" else "uf_lewin_attn_bwd"))
+    return dx, views
+
+
+def downsample_bwd(x: Tensor, dy: Tensor, w_pk_t: Tensor, B: int, H: int, W: int, add_to: Optional[Tensor] = None):
+    """Backward of Downsample (Conv2d k4 s2 p1): x f32 rows (B*H*W, Cin) (row stride may exceed Cin), dy f32 (B*H/2*W/2, Cout),
+    w_pk_t T (16 Cin, Cout).  Returns (dx -- ``add_to`` accumulated in place when given --, dW_pk f32 (Cout, 16 Cin) packed order, db)."""
+    _dev(x, dy, w_pk_t)
+    dy = _c(dy, torch.float32)
+    Cin, Cout = x.shape[1], dy.shape[1]
+    if x.stride(1) != 1:
+        x = x.contiguous()
+    dt = uf_dtype(w_pk_t.dtype)
+    dx = add_to if add_to is not None else torch.empty(B * H * W, Cin, dtype=torch.float32, device=x.device)
+    dW = torch.empty(Cout, 16 * Cin, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_downsample_bwd_workspace_bytes(B, H, W, Cin, Cout, dt)
+    ws = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_downsample_bwd(_ptr(x), x.stride(0), _ptr(dy), _ptr(_c(w_pk_t)), _ptr(dx), dx.stride(0), int(add_to is not None), _ptr(dW), _ptr(db),
+                                         B, H, W, Cin, Cout, dt, _ptr(ws), nbytes, _stream()), "uf_downsample_bwd")
+    return dx, dW, db
+
+
+def upsample_cat_bwd(d: Tensor, x: Tensor, w_pk_t: Tensor, B: int, H: int, W: int):
+    """Backward of Upsample (ConvTranspose2d k2 s2) from the gradient ``d`` (B*2H*2W, ld) of the concat buffer whose first Cout columns
+    it wrote; x f32 (B*H*W, Cin); w_pk_t T (Cin, 4 Cout).  Returns (dx f32 (B*H*W, Cin), dW_pk f32 (4 Cout, Cin) packed order, db)."""
+    _dev(d, x, w_pk_t)
+    x = _c(x, torch.float32)
+    if d.stride(1) != 1 or d.dtype != torch.float32:
+        d = d.float().contiguous()
+    Cin, Cout = x.shape[1], w_pk_t.shape[1] // 4
+    dt = uf_dtype(w_pk_t.dtype)
+    dx = torch.empty(B * H * W, Cin, dtype=torch.float32, device=x.device)
+    dW = torch.empty(4 * Cout, Cin, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_upsample_cat_bwd_workspace_bytes(B, H, W, Cin, Cout, dt)
+    ws = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_upsample_cat_bwd(_ptr(d), d.stride(0), _ptr(x), Cin, _ptr(_c(w_pk_t)), _ptr(dx), _ptr(dW), _ptr(db), B, H, W, Cin, Cout, dt,
+                                           _ptr(ws), nbytes, _stream()), "uf_upsample_cat_bwd")
+    return dx, dW, db
 
 
 def conv3x3_bwd(x: Tensor, dy_rows: Tensor, w: Tensor, B: int, H: int, W: int, nchw: bool = False, act_out: Optional[Tensor] = None, slope: float = 0.01,

@@ -66,6 +66,25 @@ class BlockPack:
         self.fused = None
         if fused:
             self.fused, self._keep = packing.pack_block(p, prefix, heads, shift, T)
+        self._train_params = None
+
+    @property
+    def train_params(self):
+        """``uf_block_train_params`` over this pack's tensors (they stay alive with the pack)."""
+        if self._train_params is None:
+            from . import _lib
+            f = lambda k: self.p[self.prefix + k].detach().float().contiguous()      # noqa: E731
+            keep = self._tp_keep = dict(norm1_w=f("norm1.weight"), norm1_b=f("norm1.bias"), norm2_w=f("norm2.weight"), norm2_b=f("norm2.bias"),
+                                        modulator=None if self.mod is None else self.mod.detach().float().contiguous(), rpb_dense=self.bias.float().contiguous(),
+                                        wqkv=self.wqkv.contiguous(), wqkv_t=self.wqkv_t, bqkv=self.bqkv.detach().float().contiguous(), wproj=self.wp.contiguous(),
+                                        wproj_t=self.wp_t, bproj=f("attn.proj.bias"), w1=self.w1.contiguous(), w1_t=self.w1_t, b1=f("mlp.linear1.0.bias"),
+                                        wdw9=self.w9.float().contiguous(), wdw9_flip=self.w9_flip.float().contiguous(), bdw=f("mlp.dwconv.0.bias"), w2_t=self.w2_t)
+            tp = _lib.BlockTrainParams()
+            for k, v in keep.items():
+                setattr(tp, k, None if v is None else v.data_ptr())
+            tp.shift, tp.heads = self.shift, self.heads
+            self._train_params = tp
+        return self._train_params
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -143,6 +162,21 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     return dx.reshape(B, L, C), g
 
 
+def _named_block_grads(prefix: str, gv: Dict[str, Tensor], C: int) -> Grads:
+    """uf_block_grads fields -> the reference's parameter names (the fused q|k|v gradient splits into to_q and to_kv)."""
+    g = {prefix + "norm1.weight": gv["norm1_w"], prefix + "norm1.bias": gv["norm1_b"], prefix + "norm2.weight": gv["norm2_w"], prefix + "norm2.bias": gv["norm2_b"],
+         prefix + "attn.relative_position_bias_table": gv["rpb_table"],
+         prefix + "attn.qkv.to_q.weight": gv["wqkv"][:C], prefix + "attn.qkv.to_kv.weight": gv["wqkv"][C:],
+         prefix + "attn.qkv.to_q.bias": gv["bqkv"][:C], prefix + "attn.qkv.to_kv.bias": gv["bqkv"][C:],
+         prefix + "attn.proj.weight": gv["wproj"], prefix + "attn.proj.bias": gv["bproj"],
+         prefix + "mlp.linear1.0.weight": gv["w1"], prefix + "mlp.linear1.0.bias": gv["b1"],
+         prefix + "mlp.dwconv.0.weight": gv["wdw"], prefix + "mlp.dwconv.0.bias": gv["bdw"],
+         prefix + "mlp.linear2.0.weight": gv["w2"], prefix + "mlp.linear2.0.bias": gv["b2"]}
+    if "modulator" in gv:
+        g[prefix + "modulator.weight"] = gv["modulator"]
+    return g
+
+
 def lewin_block_forward_backward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, dy: Tensor,
                                  dtype: torch.dtype = torch.float32) -> Tuple[Tensor, Tensor, Grads]:
     y, sv = lewin_block_forward(x, p, prefix, heads, shift, dtype)
@@ -217,8 +251,10 @@ class UformerTape:
         self.saved_blocks: List[List[Saved]] = [[] for _ in range(9)]
         self.packs: Dict[str, BlockPack] = {}
 
+        self.stage_C = [0] * 9
+
         def stage_fwd(s: int, t: Tensor) -> Tensor:                             # t: (M, C) f32 token rows
-            C = t.shape[1]
+            C = self.stage_C[s] = t.shape[1]
             for i in range(cfg.depths[s]):
                 bi = first[s] + i
                 prefix = f"{STAGES[s]}.blocks.{i}."
@@ -253,6 +289,13 @@ class UformerTape:
         return ops.output_proj(t, packing.pack_output_proj(sd["output_proj.proj.0.weight"]), sd["output_proj.proj.0.bias"], B, H, W,
                                img if cfg.dd_in == 3 else None)
 
+    def _block_ws(self, s: int) -> Tensor:
+        """one workspace for every block backward of the sweep (sized for the largest stage)"""
+        if getattr(self, "_bws", None) is None:
+            need = max(ops.lewin_block_bwd_workspace_bytes(self.B, r, r, self.stage_C[i], self.cfg.num_heads[i], self.T) for i, r in enumerate(self.res))
+            self._bws = torch.empty(need, dtype=torch.uint8, device=self.img.device)
+        return self._bws
+
     def backward(self, dy: Tensor, need_dimg: bool = True) -> Tuple[Optional[Tensor], Grads]:
         from .spec import STAGES
         sd, cfg, T, B, H, res = self.sd, self.cfg, self.T, self.B, self.H, self.res
@@ -269,10 +312,13 @@ class UformerTape:
             blocks = self.saved_blocks[s]
             while blocks:
                 sv = blocks.pop()                                                 # frees the block's saved input as the sweep passes it
-                if "x2" not in sv:                                                # recompute the intermediates from the block input
-                    pk = sv["pk"]
-                    _, sv = lewin_block_forward(sv["x"].reshape(B, res[s] * res[s], C), sd, pk.prefix, pk.heads, pk.shift, T, sv["drop"], pk, need_y=False)
-                d, gb = lewin_block_backward(sv, d)
+                if "x2" not in sv:                                                # only the block input was kept: recomputation + backward in one C call
+                    pk, dr = sv["pk"], sv["drop"]
+                    dxb, gv = ops.lewin_block_bwd(pk.train_params, sv["x"], d.reshape(-1, C), None if dr is None else dr[0], None if dr is None else dr[1],
+                                                  B, res[s], res[s], pk.heads, T, ws=self._block_ws(s))
+                    d, gb = dxb.reshape(B, res[s] * res[s], C), _named_block_grads(pk.prefix, gv, C)
+                else:
+                    d, gb = lewin_block_backward(sv, d)
                 del sv
                 g.update(gb)
                 names.extend(gb.keys())
@@ -291,22 +337,21 @@ class UformerTape:
             Cs = self.skips[3 - k].shape[1]
             cup = d.shape[1] - Cs
             dskip[3 - k] = d[:, cup:].contiguous()
-            # ConvTranspose2d k2 s2 = four independent 1x1 GEMMs: gather the 2x2 output pixels of every input pixel into one row
+            # ConvTranspose2d k2 s2 = four independent 1x1 GEMMs over the 2x2 output pixels of every input pixel (uf_upsample_cat_bwd)
             r = res[4 + k]
             w = sd[f"upsample_{k}.deconv.0.weight"]                                # (Cin, Cout, 2, 2)
-            d4 = d[:, :cup].reshape(B, r, 2, r, 2, cup).permute(0, 1, 3, 2, 4, 5).reshape(B * r * r, 4 * cup).to(T).contiguous()
-            wpk = packing.pack_upsample(w, T)                                      # (4*Cout, Cin), n = (dy*2+dx)*Cout + co
-            dWp, dbp = ops.linear_wgrad(d4, self.up_in[k].to(T))
+            wpk_t = packing.pack_upsample(w, T).t().contiguous()                   # (Cin, 4*Cout), n = (dy*2+dx)*Cout + co
+            d, dWp, g[f"upsample_{k}.deconv.0.bias"] = ops.upsample_cat_bwd(d, self.up_in[k], wpk_t, B, r, r)
             g[f"upsample_{k}.deconv.0.weight"] = dWp.reshape(2, 2, cup, w.shape[0]).permute(3, 2, 0, 1).contiguous()
-            g[f"upsample_{k}.deconv.0.bias"] = dbp.reshape(4, cup).sum(0)
             done([f"upsample_{k}.deconv.0.weight", f"upsample_{k}.deconv.0.bias"])
-            d = _input_grad(d4, wpk.t().contiguous()).float()
             self.up_in[k] = None
         d = stage_bwd(4, d, g)
         for s in reversed(range(4)):
             Cs = self.down_in[s].shape[1]
-            dx, g[f"dowsample_{s}.conv.0.weight"], g[f"dowsample_{s}.conv.0.bias"] = _conv_backward(
-                self.down_in[s], False, (B, res[s], res[s], Cs), sd[f"dowsample_{s}.conv.0.weight"], d, 2, 1, T, add_to=dskip[s])
+            wd = sd[f"dowsample_{s}.conv.0.weight"]                                  # (2C, C, 4, 4)
+            dx, dWp, g[f"dowsample_{s}.conv.0.bias"] = ops.downsample_bwd(self.down_in[s], d, packing.pack_downsample(wd, T).t().contiguous(), B, res[s], res[s],
+                                                                         add_to=dskip[s])
+            g[f"dowsample_{s}.conv.0.weight"] = dWp.reshape(wd.shape[0], 4, 4, Cs).permute(0, 3, 1, 2).contiguous()
             done([f"dowsample_{s}.conv.0.weight", f"dowsample_{s}.conv.0.bias"])
             self.down_in[s] = self.skips[s] = None
             d = stage_bwd(s, dx, g)
