@@ -22,7 +22,11 @@ unset UF_STREAMS
 (cd $R && for n in 1 2 3; do UF_STREAMS=$n python bench.py --no-cpu-baseline --no-f32-mode 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('UF_STREAMS=$n', round(d['value'],1), 'img/s')"; done) | tee $O/r02_streams.txt
 # same-box A/B against the round-1 library (ab/r01, built from the round-1 sources) when it travelled with the snapshot
 (cd $R && [ -f ab/r01/libuformer_hip.so ] && for r in 1 2; do for v in r01 r02; do if [ $v = r01 ]; then export UFORMER_HIP_LIB=$R/ab/r01/libuformer_hip.so UF_ALLOW_OLDER_LIB=1; else unset UFORMER_HIP_LIB UF_ALLOW_OLDER_LIB; fi; python bench.py --no-cpu-baseline --no-f32-mode 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v run $r', round(d['value'],1), 'img/s', round(d['ms_per_step'],3), 'ms')"; done; done; unset UFORMER_HIP_LIB UF_ALLOW_OLDER_LIB) | tee $O/r02_ab_vs_r01.txt
-(cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 1 2>/dev/null | tail -1) | tee $O/r02_train_step.json
+(cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 2>/dev/null | tail -1) | tee $O/r02_train_step.json
+(cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 --sink 2>/dev/null | tail -1) | tee $O/r02_train_step_sink.json
+rocprofv3 --kernel-trace --stats -d /tmp/ktt -o ktt -- python $R/scripts/train_bench.py --batch 32 --steps 2 --warmup 1 > $O/ktt.log 2>&1
+python $R/scripts/rocprof_summary.py /tmp/ktt/ktt_results.db $O/r02_train_final | tail -2
+(cd $R && python scripts/ubench_train.py all 2>/dev/null | grep -v amdgpu.ids) > $O/r02_ubench_train.txt; tail -1 $O/r02_ubench_train.txt
 (cd $R && python bench.py --error-budget --kernels-json $O/r02_kernels_hip_events.json > $O/r02_bench.json 2> $O/bench.err; cut -c1-700 $O/r02_bench.json)
 (cd $R && python bench.py --img 1280 --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode 2>/dev/null | cut -c1-400) | tee $O/r02_bench_720p.json
 ls -la $O
