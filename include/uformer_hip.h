@@ -334,6 +334,27 @@ typedef struct uf_block_grads {
     float* wdw;   float* bdw;    /* (4C,1,3,3), (4C) */
     float* w2;    float* b2;     /* (C,4C), (C) */
 } uf_block_grads;
+/* Per-step packing of one block for training: the reference's f32 parameter tensors (device pointers; they must stay unchanged
+ * until the block's backward has run) -> every operand layout the fused forward (uf_block_params) and the block-level backward
+ * (uf_block_train_params) read, written into ONE caller buffer in 5 launches.  The small f32 tensors (LayerNorm, biases, modulator)
+ * are referenced in place.  index_is_standard: the caller has verified that relative_position_index is the reference's
+ * (model.py:471-481) -- the compact Toeplitz bias table the fused attention kernel wants is only valid then (else rpb_tab = NULL
+ * and the forward takes the 3-kernel path with the dense table). */
+typedef struct uf_block_raw_params {
+    const float* norm1_w;  const float* norm1_b;  const float* norm2_w;  const float* norm2_b;
+    const float* modulator;                 /* (64,C) or NULL */
+    const float* rpb_table;                 /* (225, heads) */
+    const int64_t* rpb_index;               /* (64, 64) */
+    const float* to_q_w;   const float* to_q_b;   const float* to_kv_w;  const float* to_kv_b;    /* (C,C) (C) (2C,C) (2C) */
+    const float* proj_w;   const float* proj_b;
+    const float* lin1_w;   const float* lin1_b;   /* (4C,C) (4C) */
+    const float* dw_w;     const float* dw_b;     /* (4C,1,3,3) (4C) */
+    const float* lin2_w;   const float* lin2_b;   /* (C,4C) (C) */
+    int32_t index_is_standard;
+} uf_block_raw_params;
+size_t uf_pack_block_train_bytes(int C, int heads, uf_dtype dtype);
+int uf_pack_block_train(const uf_block_raw_params* raw, int C, int heads, int shift, uf_dtype dtype, void* buf, size_t buf_bytes,
+                        uf_block_params* fwd /* may be NULL */, uf_block_train_params* bwd /* may be NULL */, void* stream);
 size_t uf_lewin_block_bwd_workspace_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype);   /* serves all three below */
 /* x: the block input f32[B*H*W][C]; dy: gradient of the block output; dx: gradient of the input (may NOT alias); drop_*: the
  * per-image DropPath scales the forward used (f32[B]) or NULL.  model.py:951-987. */

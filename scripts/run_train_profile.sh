@@ -1,3 +1,4 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
 python -m pytest tests/test_gpu_bwd.py -q -x 2>&1 | tail -15 > $O/t_gpu.txt; cat $O/t_gpu.txt
-python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 2>&1 | tail -3 | tee $O/tb.txt
+python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 2>&1 | tail -1 | tee $O/tb.txt
+UF_PY_PACK=1 python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 2>&1 | tail -1 | tee -a $O/tb.txt

@@ -455,3 +455,28 @@ def test_block_level_backward_entry_points(dtype):
         assert torch.equal(g_l[k], gv[k]), k
     for k in ("norm1_w", "norm1_b", "modulator", "rpb_table", "wqkv", "bqkv", "wproj", "bproj"):
         assert torch.equal(g_a[k], gv[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_native_block_pack_equals_the_aten_packing(dtype):
+    """uf_pack_block_train (5 launches) against uformer_amd.packing / train.BlockPack (ATen casts, transposes, gathers): the fused
+    forward and the block-level backward must give identical bits on either pack."""
+    from uformer_amd import ops, spec, train
+    B, H, C, heads, shift = 2, 16, 64, 2, 4
+    cfg = spec.arch_config("tiny32", 128)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 12).items()}
+    prefix = "decoderlayer_3.blocks.0."
+    py = train.BlockPack(sd, prefix, heads, shift, dtype, fused=True)
+    nat = train.NativeBlockPack(sd, prefix, heads, shift, dtype)
+    assert nat.fused.rpb_tab is not None                                      # the reference's index buffer: Toeplitz table in use
+    x = torch.randn(B * H * H, C, generator=g(110)).cuda()
+    dy = torch.randn(B * H * H, C, generator=g(111)).cuda()
+    drop = torch.tensor([[1.25, 0.0], [1.25, 1.25]]).cuda()
+    y1 = ops.lewin_block_train_fwd(py.fused, x, B, H, H, dtype, drop[0], drop[1])
+    y2 = ops.lewin_block_train_fwd(nat.fused, x, B, H, H, dtype, drop[0], drop[1])
+    assert torch.equal(y1, y2)
+    dx1, g1 = ops.lewin_block_bwd(py.train_params, x, dy, drop[0], drop[1], B, H, H, heads, dtype)
+    dx2, g2 = ops.lewin_block_bwd(nat.train_params, x, dy, drop[0], drop[1], B, H, H, heads, dtype)
+    assert torch.equal(dx1, dx2)
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k

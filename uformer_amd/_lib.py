@@ -33,6 +33,13 @@ class BlockTrainParams(C.Structure):
         "w1", "w1_t", "b1", "wdw9", "wdw9_flip", "bdw", "w2_t")] + [("shift", C.c_int32), ("heads", C.c_int32)]
 
 
+class BlockRawParams(C.Structure):
+    """``uf_block_raw_params`` (include/uformer_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_w", "norm1_b", "norm2_w", "norm2_b", "modulator", "rpb_table", "rpb_index", "to_q_w", "to_q_b", "to_kv_w", "to_kv_b", "proj_w", "proj_b",
+        "lin1_w", "lin1_b", "dw_w", "dw_b", "lin2_w", "lin2_b")] + [("index_is_standard", C.c_int32)]
+
+
 class BlockGrads(C.Structure):
     """``uf_block_grads`` (include/uformer_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
@@ -103,6 +110,8 @@ SIGNATURES = {
     "uf_rpb_table_grad": (I, [P, P, I, P]),
     "uf_im2col": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, P]),
     "uf_col2im": (I, [P, I, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "uf_pack_block_train_bytes": (C.c_size_t, [I, I, I]),
+    "uf_pack_block_train": (I, [P, I, I, I, I, P, C.c_size_t, P, P, P]),
     "uf_lewin_block_bwd_workspace_bytes": (C.c_size_t, [I, I, I, I, I, I]),
     "uf_lewin_block_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),
     "uf_leff_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, C.c_size_t, P]),

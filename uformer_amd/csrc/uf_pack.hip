@@ -1,0 +1,158 @@
+// Per-step operand packing of one LeWin block for training (row a15): the reference's f32 parameter tensors -> every layout the
+// fused forward and the block-level backward read, in 5 launches (4 matrices + 1 for the vectors / tables) instead of ~50 ATen
+// casts, transposes, cats, gathers and clones per block (the weights change every optimizer step, so this runs 40 times per step:
+// it was 10 % of the GPU time of a training step, all of it 3-5 us kernels).
+//   matrix W (N,K) f32 [rows from up to two tensors: to_q | to_kv]  ->  T row-major, T transposed (K,N), T fragment-major
+//   bqkv = cat(to_q.bias, to_kv.bias); taps (4C,1,3,3) -> (9,4C) and the same with the tap axis reversed;
+//   dense relative-position bias (heads,64,64) = table[index] (model.py:500-502) and the compact Toeplitz table (heads,15,15)
+#include "uf_internal.h"
+
+namespace uf {
+namespace {
+
+template <typename T> __device__ __forceinline__ void store8_t(T* p, const float* f);
+template <> __device__ __forceinline__ void store8_t<bf16>(bf16* p, const float* f) {
+    *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+template <> __device__ __forceinline__ void store8_t<float>(float* p, const float* f) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+}
+
+// thread = 8 consecutive k of one row n.  K % 32 == 0, N % 16 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ src0, int n0, const float* __restrict__ src1, int N, int K,
+                                                          T* __restrict__ plain, T* __restrict__ transposed, T* __restrict__ fm) {
+    const int kc = K / 8;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * kc) return;
+    const int n = (int)(idx / kc), k = (int)(idx % kc) * 8;
+    const float* row = n < n0 ? src0 + (size_t)n * K : src1 + (size_t)(n - n0) * K;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + k), b = *reinterpret_cast<const f32x4*>(row + k + 4);
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    if (plain) store8_t<T>(plain + (size_t)n * K + k, f);
+    if (fm) {
+        const int KS = K / 32;
+        store8_t<T>(fm + ((((size_t)(n >> 4) * KS + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3), f);
+    }
+    if (transposed) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) store1(transposed + (size_t)(k + e) * N + n, f[e]);
+    }
+}
+
+struct SmallPack {
+    const float *qb, *kvb, *dw, *table;
+    const long long* index;
+    float *bqkv, *w9, *w9_flip, *dense, *tab;
+    int C, heads;
+};
+
+__global__ __launch_bounds__(256) void pack_small_kernel(const SmallPack p) {
+    const int C = p.C, C4 = 4 * C;
+    const int n_b = 3 * C, n_w = 9 * C4, n_d = p.heads * 4096, n_t = p.heads * 225;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_b + 2 * n_w + n_d + n_t; i += gridDim.x * 256) {
+        int j = i;
+        if (j < n_b) { p.bqkv[j] = j < C ? p.qb[j] : p.kvb[j - C]; continue; }
+        j -= n_b;
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9[j] = p.dw[c * 9 + t]; continue; }                 // (4C,1,3,3) -> (9,4C)
+        j -= n_w;
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9_flip[j] = p.dw[c * 9 + 8 - t]; continue; }
+        j -= n_w;
+        if (j < n_d) { const int h = j >> 12, qk = j & 4095; p.dense[j] = p.table[(size_t)p.index[qk] * p.heads + h]; continue; }
+        j -= n_d;
+        {   // tab[h][dy+7][7-dx] = table[(dy+7)*15 + (dx+7)][h]   (the reference's relative_position_index, model.py:471-481)
+            const int h = j / 225, r = j - h * 225, a = r / 15, b = r - a * 15;
+            p.tab[j] = p.table[(size_t)(a * 15 + (14 - b)) * p.heads + h];
+        }
+    }
+}
+
+struct PackPlan {
+    size_t wqkv, wqkv_t, wqkv_fm, wp, wp_t, wp_fm, w1, w1_t, w1_fm, w2, w2_t, w2_fm, bqkv, w9, w9_flip, dense, tab, total;
+};
+
+PackPlan plan_pack(int C, int heads, uf_dtype dtype) {
+    const size_t sz = dtype_size(dtype), c2 = (size_t)C * C;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { off = align_up(off, 256); const size_t o = off; off += bytes; return o; };
+    PackPlan p;
+    p.wqkv = take(3 * c2 * sz); p.wqkv_t = take(3 * c2 * sz); p.wqkv_fm = take(3 * c2 * sz);
+    p.wp = take(c2 * sz);       p.wp_t = take(c2 * sz);       p.wp_fm = take(c2 * sz);
+    p.w1 = take(4 * c2 * sz);   p.w1_t = take(4 * c2 * sz);   p.w1_fm = take(4 * c2 * sz);
+    p.w2 = take(4 * c2 * sz);   p.w2_t = take(4 * c2 * sz);   p.w2_fm = take(4 * c2 * sz);
+    p.bqkv = take((size_t)3 * C * 4); p.w9 = take((size_t)36 * C * 4); p.w9_flip = take((size_t)36 * C * 4);
+    p.dense = take((size_t)heads * 4096 * 4); p.tab = take((size_t)heads * 225 * 4);
+    p.total = align_up(off, 256);
+    return p;
+}
+
+template <typename T>
+void launch_pack_linear(const float* s0, int n0, const float* s1, int N, int K, void* plain, void* tr, void* fm, hipStream_t st) {
+    const long long n = (long long)N * (K / 8);
+    hipLaunchKernelGGL(pack_linear_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s0, n0, s1, N, K, (T*)plain, (T*)tr, (T*)fm);
+}
+
+}  // namespace
+}  // namespace uf
+
+using namespace uf;
+
+extern "C" size_t uf_pack_block_train_bytes(int C, int heads, uf_dtype dtype) {
+    if (C <= 0 || heads <= 0 || (dtype != UF_BF16 && dtype != UF_F32)) return 0;
+    return plan_pack(C, heads, dtype).total;
+}
+
+extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int heads, int shift, uf_dtype dtype, void* buf, size_t buf_bytes,
+                                   uf_block_params* fwd, uf_block_train_params* bwd, void* stream) {
+    UF_REQUIRE(raw && buf && (fwd || bwd), UF_ERR_NULL, "uf_pack_block_train: null pointer");
+    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_pack_block_train: dtype %d", (int)dtype);
+    UF_REQUIRE(C >= 32 && C % 32 == 0 && heads > 0 && C % heads == 0, UF_ERR_SHAPE, "uf_pack_block_train: C=%d heads=%d (C a multiple of 32)", C, heads);
+    UF_REQUIRE(raw->norm1_w && raw->norm1_b && raw->norm2_w && raw->norm2_b && raw->rpb_table && raw->rpb_index && raw->to_q_w && raw->to_q_b && raw->to_kv_w &&
+                   raw->to_kv_b && raw->proj_w && raw->proj_b && raw->lin1_w && raw->lin1_b && raw->dw_w && raw->dw_b && raw->lin2_w && raw->lin2_b,
+               UF_ERR_NULL, "uf_pack_block_train: a parameter pointer is NULL (only modulator may be)");
+    const PackPlan pl = plan_pack(C, heads, dtype);
+    UF_REQUIRE(buf_bytes >= pl.total && ((uintptr_t)buf % 256) == 0, UF_ERR_WORKSPACE, "uf_pack_block_train: buffer %zu < %zu bytes (256-byte aligned)", buf_bytes, pl.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* b = (char*)buf;
+    auto at = [&](size_t o) { return (void*)(b + o); };
+    if (dtype == UF_BF16) {
+        launch_pack_linear<bf16>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
+        launch_pack_linear<bf16>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
+        launch_pack_linear<bf16>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
+        launch_pack_linear<bf16>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
+    } else {
+        launch_pack_linear<float>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
+        launch_pack_linear<float>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
+        launch_pack_linear<float>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
+        launch_pack_linear<float>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
+    }
+    SmallPack sp{raw->to_q_b, raw->to_kv_b, raw->dw_w, raw->rpb_table, (const long long*)raw->rpb_index,
+                 (float*)at(pl.bqkv), (float*)at(pl.w9), (float*)at(pl.w9_flip), (float*)at(pl.dense), (float*)at(pl.tab), C, heads};
+    const int n_small = 3 * C + 72 * C + heads * (4096 + 225);
+    hipLaunchKernelGGL(pack_small_kernel, dim3((n_small + 255) / 256), dim3(256), 0, st, sp);
+    if (int rc = check_launch("pack_block_train")) return rc;
+    if (fwd) {
+        *fwd = uf_block_params{};
+        fwd->norm1_w = raw->norm1_w; fwd->norm1_b = raw->norm1_b; fwd->modulator = raw->modulator;
+        fwd->rpb_dense = (const float*)at(pl.dense); fwd->rpb_fm = nullptr; fwd->rpb_tab = raw->index_is_standard ? (const float*)at(pl.tab) : nullptr;
+        fwd->wqkv_fm = at(pl.wqkv_fm); fwd->bqkv = (const float*)at(pl.bqkv);
+        fwd->wproj = at(pl.wp); fwd->wproj_fm = at(pl.wp_fm); fwd->bproj = raw->proj_b;
+        fwd->norm2_w = raw->norm2_w; fwd->norm2_b = raw->norm2_b;
+        fwd->w1_fm = at(pl.w1_fm); fwd->b1 = raw->lin1_b; fwd->wdw9 = (const float*)at(pl.w9); fwd->bdw = raw->dw_b;
+        fwd->w2_fm = at(pl.w2_fm); fwd->b2 = raw->lin2_b;
+        fwd->shift = shift; fwd->heads = heads;
+    }
+    if (bwd) {
+        *bwd = uf_block_train_params{};
+        bwd->norm1_w = raw->norm1_w; bwd->norm1_b = raw->norm1_b; bwd->norm2_w = raw->norm2_w; bwd->norm2_b = raw->norm2_b;
+        bwd->modulator = raw->modulator; bwd->rpb_dense = (const float*)at(pl.dense);
+        bwd->wqkv = at(pl.wqkv); bwd->wqkv_t = at(pl.wqkv_t); bwd->bqkv = (const float*)at(pl.bqkv);
+        bwd->wproj = at(pl.wp); bwd->wproj_t = at(pl.wp_t); bwd->bproj = raw->proj_b;
+        bwd->w1 = at(pl.w1); bwd->w1_t = at(pl.w1_t); bwd->b1 = raw->lin1_b;
+        bwd->wdw9 = (const float*)at(pl.w9); bwd->wdw9_flip = (const float*)at(pl.w9_flip); bwd->bdw = raw->dw_b;
+        bwd->w2_t = at(pl.w2_t);
+        bwd->shift = shift; bwd->heads = heads;
+    }
+    return UF_OK;
+}

@@ -87,6 +87,58 @@ class BlockPack:
         return self._train_params
 
 
+_STD_INDEX: Dict[Tuple[int, int], bool] = {}
+
+
+def _index_is_standard(idx: Tensor) -> bool:
+    """relative_position_index equals the reference's (model.py:471-481)?  Checked once per buffer (it is a constant)."""
+    key = (idx.data_ptr(), idx._version)
+    ok = _STD_INDEX.get(key)
+    if ok is None:
+        from .spec import relative_position_index
+        ok = _STD_INDEX[key] = bool(idx.shape == (64, 64) and torch.equal(idx.detach().cpu().long(), relative_position_index(8)))
+    return ok
+
+
+class NativeBlockPack:
+    """The per-step operand pack of one block made by ``uf_pack_block_train`` (5 launches into one buffer): ``fused`` is the
+    ``uf_block_params`` of the fused forward, ``train_params`` the ``uf_block_train_params`` of the block-level backward.  The small
+    f32 parameters are referenced in place: the pack is valid until the parameters change (the optimizer step)."""
+
+    def __init__(self, p: Dict[str, Tensor], prefix: str, heads: int, shift: int, T: torch.dtype):
+        from . import _lib
+        self.prefix, self.heads, self.shift, self.T = prefix, heads, shift, T
+        f = lambda k: p[prefix + k].detach()                                   # noqa: E731
+        names = dict(norm1_w="norm1.weight", norm1_b="norm1.bias", norm2_w="norm2.weight", norm2_b="norm2.bias", rpb_table="attn.relative_position_bias_table",
+                     rpb_index="attn.relative_position_index", to_q_w="attn.qkv.to_q.weight", to_q_b="attn.qkv.to_q.bias", to_kv_w="attn.qkv.to_kv.weight",
+                     to_kv_b="attn.qkv.to_kv.bias", proj_w="attn.proj.weight", proj_b="attn.proj.bias", lin1_w="mlp.linear1.0.weight", lin1_b="mlp.linear1.0.bias",
+                     dw_w="mlp.dwconv.0.weight", dw_b="mlp.dwconv.0.bias", lin2_w="mlp.linear2.0.weight", lin2_b="mlp.linear2.0.bias")
+        keep = self._keep = {}
+        raw = _lib.BlockRawParams()
+        for field, key in names.items():
+            t = f(key)
+            t = t.contiguous() if field == "rpb_index" else t.float().contiguous()
+            if field == "rpb_index" and t.dtype != torch.int64:
+                t = t.long()
+            keep[field] = t
+            setattr(raw, field, t.data_ptr())
+        if (prefix + "modulator.weight") in p:
+            keep["modulator"] = f("modulator.weight").float().contiguous()
+            raw.modulator = keep["modulator"].data_ptr()
+        raw.index_is_standard = int(_index_is_standard(keep["rpb_index"]))
+        C = keep["norm1_w"].numel()
+        dev = keep["norm1_w"].device
+        lib = _lib.load()
+        dt = ops.uf_dtype(T)
+        nbytes = lib.uf_pack_block_train_bytes(C, heads, dt)
+        self._buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.fused, self.train_params = _lib.BlockParams(), _lib.BlockTrainParams()
+        import ctypes
+        with torch.cuda.device(dev):
+            _lib.check(lib.uf_pack_block_train(ctypes.byref(raw), C, heads, shift, dt, self._buf.data_ptr(), nbytes, ctypes.byref(self.fused),
+                                               ctypes.byref(self.train_params), torch.cuda.current_stream().cuda_stream), "uf_pack_block_train")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # LeWin block (model.py:908-989)
 # ------------------------------------------------------------------------------------------------------------------
@@ -259,7 +311,9 @@ class UformerTape:
                 bi = first[s] + i
                 prefix = f"{STAGES[s]}.blocks.{i}."
                 dr = self.drop[2 * bi:2 * bi + 2] if self.drop is not None else None
-                pk = self.packs[prefix] = BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=self.recompute)
+                native = self.recompute and C % 32 == 0 and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
+                pk = self.packs[prefix] = (NativeBlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T) if native else
+                                           BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=self.recompute))
                 if self.recompute:                                              # fused kernels; the block's input is all that is kept
                     y = ops.lewin_block_train_fwd(pk.fused, t, B, res[s], res[s], T, None if dr is None else dr[0], None if dr is None else dr[1])
                     self.saved_blocks[s].append(dict(x=t, drop=dr, pk=pk))
