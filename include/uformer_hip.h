@@ -237,6 +237,12 @@ int uf_linear_mul_dgelu(const void* A, const void* W, const float* bias, const v
 size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);
 int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
                      float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream);
+/* the same backward reading the output gradient where the block backward has it: dy of the operand type (dy_is_f32 = 1: f32), in WINDOW
+ * order when `windowed` (x, add and dx rows are then the tokens of those window rows: window_reverse + roll back folded in), plus an
+ * optional second gradient `add` f32 (stride ld_dx) summed into dx (the residual path).  Same workspace. */
+int uf_layernorm_bwd_fused(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32,
+                           const float* add, float* dx, int ld_dx, float* dgamma, float* dbeta, int B, int H, int W, int C,
+                           int windowed, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 /* nn.Linear weight / bias gradients: dW f32[N][K] = sum_m dY[m][n] X[m][k], db f32[N] = sum_m dY[m][n] (db may be NULL),
  * OVERWRITTEN.  dY T[M][ldy] (N columns), X T[M][ldx] (K columns); N, K, ldy, ldx multiples of 16 bytes / sizeof(T).
  * (The input gradient dX = dY W is uf_linear_fwd with the transposed weight.) */

@@ -70,10 +70,20 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ a, 
 // Row layout as the forward kernel: LPR lanes share a row (DPP all-reduce), RPB rows per workgroup pass; a thread keeps
 // the same channels over all its rows, so dgamma/dbeta accumulate in registers and land in partial[slot][2][C].
 // ---------------------------------------------------------------------------------------------------------------
-template <int C>
+// dy: f32 or the operand type (TD); rows of dy are indexed by m, rows of x / add / dx by tok(m) = m, or -- win_h > 0 -- the token of
+// window-order row m (dy still in the order the attention half produced it: window_reverse + roll back folded in); add (optional):
+// a second gradient of the same tensor summed into dx (the residual path).
+template <typename TD> __device__ __forceinline__ f32x4 load_dy4(const TD* p);
+template <> __device__ __forceinline__ f32x4 load_dy4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load_dy4<bf16>(const bf16* p) {
+    const u32x2 r = *reinterpret_cast<const u32x2*>(p);
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+}
+
+template <int C, typename TD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ dy, int ld_dy, float* __restrict__ dx, int ld_dx,
-                                                            float* __restrict__ partial, int rows) {
+                                                            const TD* __restrict__ dy, int ld_dy, const float* __restrict__ add, float* __restrict__ dx, int ld_dx,
+                                                            float* __restrict__ partial, int rows, int win_h, int win_w, int shift) {
     constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
     constexpr int V4 = C / (4 * LPR);
     constexpr int RPB = 256 / LPR;
@@ -90,12 +100,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const int m = mb * RPB + rl;
         const bool live = m < rows;
         const int mc = live ? m : rows - 1;                        // clamped: loads stay unconditional
+        const int tok = win_h > 0 ? window_row_to_token(mc, win_h, win_w, shift) : mc;
         f32x4 v[V4], d[V4];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
-            v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)mc * ld_x + (i * LPR + sub) * 4);
-            d[i] = *reinterpret_cast<const f32x4*>(dy + (size_t)mc * ld_dy + (i * LPR + sub) * 4);
+            v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)tok * ld_x + (i * LPR + sub) * 4);
+            d[i] = load_dy4<TD>(dy + (size_t)mc * ld_dy + (i * LPR + sub) * 4);
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         const float mean = allreduce<RedSum, LPR>(sum) * (1.0f / C);
@@ -120,7 +131,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (live) {
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
-                *reinterpret_cast<f32x4*>(dx + (size_t)m * ld_dx + (i * LPR + sub) * 4) = (d[i] * gm[i] - s1 - v[i] * s2) * rstd;
+                f32x4 r = (d[i] * gm[i] - s1 - v[i] * s2) * rstd;
+                if (add) r = r + *reinterpret_cast<const f32x4*>(add + (size_t)tok * ld_dx + (i * LPR + sub) * 4);
+                *reinterpret_cast<f32x4*>(dx + (size_t)tok * ld_dx + (i * LPR + sub) * 4) = r;
                 adg[i] += d[i] * v[i];
                 adb[i] += d[i];
             }
@@ -146,7 +159,14 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
     if (j < n) {
         const float* src = partial + j;
         int p = pl;
-        for (; p + 24 < P; p += 32) {       // four independent loads in flight per thread
+        for (; p + 56 < P; p += 64) {       // eight independent loads in flight per thread: the kernel is a chain of L2 round trips (P / 8 partials
+            float v[8];                     // per thread), 560 launches per training step, 8 ms of it with four in flight
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(p + 8 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p + 24 < P; p += 32) {
             const float a = src[(size_t)p * stride], b = src[(size_t)(p + 8) * stride], c = src[(size_t)(p + 16) * stride], d = src[(size_t)(p + 24) * stride];
             s = (((s + a) + b) + c) + d;
         }
@@ -727,12 +747,15 @@ extern "C" size_t uf_layernorm_bwd_workspace_bytes(int rows, int C) {
     return (size_t)LN_BWD_MAX_BLOCKS * (256 / LPR) * 2 * C * sizeof(float);
 }
 
-extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
-                                float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream) {
-    UF_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, UF_ERR_NULL, "uf_layernorm_bwd: null pointer");
+static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32, uf_dtype dtype, const float* add,
+                             float* dx, int ld_dx, float* dgamma, float* dbeta, int rows, int C, int win_h, int win_w, int shift, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, UF_ERR_NULL, "%s: null pointer", fn);
     UF_REQUIRE(rows > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, UF_ERR_SHAPE,
-               "uf_layernorm_bwd: rows=%d C=%d ld=(%d,%d,%d)", rows, C, ld_x, ld_dy, ld_dx);
-    UF_REQUIRE(ws_bytes >= uf_layernorm_bwd_workspace_bytes(rows, C), UF_ERR_WORKSPACE, "uf_layernorm_bwd: workspace too small");
+               "%s: rows=%d C=%d ld=(%d,%d,%d)", fn, rows, C, ld_x, ld_dy, ld_dx);
+    UF_REQUIRE(win_h == 0 || (win_h % 8 == 0 && win_w % 8 == 0 && win_w > 0 && rows % (win_h * win_w) == 0 && (shift == 0 || shift == 4)), UF_ERR_SHAPE,
+               "%s: window geometry H=%d W=%d shift=%d rows=%d", fn, win_h, win_w, shift, rows);
+    UF_REQUIRE(ws_bytes >= uf_layernorm_bwd_workspace_bytes(rows, C), UF_ERR_WORKSPACE, "%s: workspace too small", fn);
+    const bool f32dy = dy_is_f32 || dtype == UF_F32;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)ws;
     int slots = 0;
@@ -741,7 +764,8 @@ extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, co
         constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64, RPB = 256 / LPR;                                                   \
         const int nblk = (rows + RPB - 1) / RPB, grid = nblk < LN_BWD_MAX_BLOCKS ? nblk : LN_BWD_MAX_BLOCKS;                  \
         slots = grid * RPB;                                                                                                   \
-        hipLaunchKernelGGL(layernorm_bwd_kernel<CV>, dim3(grid), dim3(256), 0, st, x, ld_x, gamma, dy, ld_dy, dx, ld_dx, partial, rows); \
+        if (f32dy) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, float>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const float*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<CV, bf16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const bf16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
         break;                                                                                                                \
     }
     switch (C) {
@@ -753,7 +777,7 @@ extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, co
         UF_LNB_CASE(512)
         UF_LNB_CASE(1024)
         default:
-            set_error("uf_layernorm_bwd: C=%d unsupported (16,32,64,128,256,512,1024)", C);
+            set_error("%s: C=%d unsupported (16,32,64,128,256,512,1024)", fn, C);
             return UF_ERR_UNSUPPORTED;
     }
 #undef UF_LNB_CASE
@@ -762,6 +786,23 @@ extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, co
     hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial, slots, (size_t)2 * C, dgamma, C);
     hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial + C, slots, (size_t)2 * C, dbeta, C);
     return check_launch("layernorm_bwd_finalize");
+}
+
+extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* dy, int ld_dy, float* dx, int ld_dx,
+                                float* dgamma, float* dbeta, int rows, int C, void* ws, size_t ws_bytes, void* stream) {
+    return layernorm_bwd_any("uf_layernorm_bwd", x, ld_x, gamma, dy, ld_dy, 1, UF_F32, nullptr, dx, ld_dx, dgamma, dbeta, rows, C, 0, 0, 0, ws, ws_bytes, stream);
+}
+
+// the same backward reading the output gradient where the block backward has it: dy of the operand type (dtype; dy_is_f32 = 1: f32) in
+// window order when windowed (B, H, W, shift: x, add and dx rows are then the tokens of those window rows: window_reverse + roll back folded
+// in), plus an optional second gradient `add` f32[rows][ld_dx] summed into dx (the residual path).  Saves the cast and add passes.
+extern "C" int uf_layernorm_bwd_fused(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32, const float* add, float* dx, int ld_dx,
+                                      float* dgamma, float* dbeta, int B, int H, int W, int C, int windowed, int shift, uf_dtype dtype, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && (dtype == UF_BF16 || dtype == UF_F32), UF_ERR_SHAPE, "uf_layernorm_bwd_fused: B=%d H=%d W=%d dtype=%d", B, H, W, (int)dtype);
+    UF_REQUIRE(dy_is_f32 || dtype == UF_F32 || ld_dy % 8 == 0, UF_ERR_ALIGN, "uf_layernorm_bwd_fused: ld_dy=%d", ld_dy);
+    return layernorm_bwd_any("uf_layernorm_bwd_fused", x, ld_x, gamma, dy, ld_dy, dy_is_f32, dtype, add, dx, ld_dx, dgamma, dbeta, B * H * W, C, windowed ? H : 0, windowed ? W : 0,
+                             shift, ws, ws_bytes, stream);
 }
 
 extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {

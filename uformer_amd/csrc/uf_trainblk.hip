@@ -31,8 +31,8 @@ struct BlockPlan {
     void *xn, *q, *k, *vt, *o, *tA, *tB;      // tA: yw -> dyT -> dyw -> dxn;  tB: z -> dzT -> dO      (each T[M][C])
     void *a1, *h1, *c, *g2, *dc;              // T[M][4C]; g2 is reused for da1
     void* dqkv;                               // T[M][3C]
-    float *x1, *fA, *fB;                      // f32[M][C]: x1;  fA: dzf -> dln;  fB: dx1ln -> dx1 (in place)
-    float *dbias, *dw9, *zero;                // f32[heads*4096], f32[9*4C + 4C... see below], f32[4C] zeros
+    float *x1, *fB;                           // f32[M][C]: x1;  fB: dx1ln -> dx1 (in place)
+    float *dbias, *dw9, *zero;                // f32[heads*4096], f32[9][4C] tap-major dwconv gradient, f32[4C] zeros (bias of the input-gradient GEMMs)
     void* scratch; size_t scratch_bytes;      // workspace of the op kernels (max over them)
     size_t total;
 };
@@ -61,7 +61,7 @@ BlockPlan plan_block(void* ws, int B, int H, int W, int C, int heads, uf_dtype d
     p.a1 = b.take<void>(M * 4 * C * sz); p.h1 = b.take<void>(M * 4 * C * sz); p.c = b.take<void>(M * 4 * C * sz);
     p.g2 = b.take<void>(M * 4 * C * sz); p.dc = b.take<void>(M * 4 * C * sz);
     p.dqkv = b.take<void>(M * 3 * C * sz);
-    p.x1 = b.take<float>(M * C * 4); p.fA = b.take<float>(M * C * 4); p.fB = b.take<float>(M * C * 4);
+    p.x1 = b.take<float>(M * C * 4); p.fB = b.take<float>(M * C * 4);
     p.dbias = b.take<float>((size_t)heads * 4096 * 4);
     p.dw9 = b.take<float>((size_t)9 * 4 * C * 4);
     p.zero = b.take<float>((size_t)4 * C * 4);
@@ -134,8 +134,7 @@ int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const flo
     UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.g2, B, H, W, C4, dtype, st));                             // da1 (over g2)
     UF_TRY(uf_linear_wgrad(pl.g2, C4, pl.tB, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch, pl.scratch_bytes, st));       // tB still holds z
     UF_TRY(uf_linear_fwd(pl.g2, p->w1_t, pl.zero, pl.tB, M, C, C4, 0, dtype, st));                                         // dz (over z)
-    UF_TRY(uf_residual_combine(nullptr, pl.tB, 0, pl.fA, nullptr, B, H, W, C, 0, 0, dtype, st));                          // to f32
-    UF_TRY(uf_layernorm_bwd(x1, C, p->norm2_w, pl.fA, C, pl.fB, C, g->norm2_w, g->norm2_b, M, C, pl.scratch, pl.scratch_bytes, st));
+    UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tB, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
     return UF_OK;
 }
 
@@ -155,9 +154,8 @@ int backward_attn(const uf_block_train_params* p, const BlockPlan& pl, const flo
         UF_REQUIRE(g->modulator, UF_ERR_NULL, "block backward: the block has a modulator but grads->modulator is NULL");
         UF_TRY(uf_rows_sum(pl.tA, 64 * C, g->modulator, M / 64, 64 * C, dtype, pl.scratch, pl.scratch_bytes, st));
     }
-    UF_TRY(uf_residual_combine(nullptr, pl.tA, 0, pl.fA, nullptr, B, H, W, C, 1, p->shift, dtype, st));                   // window_reverse + roll back, f32
-    UF_TRY(uf_layernorm_bwd(x, C, p->norm1_w, pl.fA, C, dx, C, g->norm1_w, g->norm1_b, M, C, pl.scratch, pl.scratch_bytes, st));
-    UF_TRY(uf_residual_combine(dx, dx1, 1, dx, nullptr, B, H, W, C, 0, 0, dtype, st));                                    // + the residual path
+    // LN1 backward reads dxn in window order (window_reverse + roll back folded in) and adds the residual path's gradient
+    UF_TRY(uf_layernorm_bwd_fused(x, C, p->norm1_w, pl.tA, C, 0, dx1, dx, C, g->norm1_w, g->norm1_b, B, H, W, C, 1, p->shift, dtype, pl.scratch, pl.scratch_bytes, st));
     return UF_OK;
 }
 

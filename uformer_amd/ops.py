@@ -330,6 +330,26 @@ def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor):
     return dx.reshape(x.shape), dg, db
 
 
+def layernorm_bwd_fused(x: Tensor, gamma: Tensor, dy: Tensor, B: int, H: int, W: int, add: Optional[Tensor] = None, windowed: bool = False, shift: int = 0):
+    """layernorm_bwd reading dy (bf16 or f32 rows, in WINDOW order when ``windowed``) where the block backward has it, with an optional
+    second gradient ``add`` (f32) summed into dx: returns (dx f32 (B*H*W, C) raster rows, dgamma, dbeta)."""
+    _dev(x, gamma, dy)
+    Cc = x.shape[-1]
+    x2, dy2 = _c(x, torch.float32).reshape(-1, Cc), _c(dy).reshape(-1, Cc)
+    add2 = None if add is None else _c(add, torch.float32).reshape(-1, Cc)
+    dx = torch.empty_like(x2)
+    dg = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    nbytes = lib.uf_layernorm_bwd_workspace_bytes(x2.shape[0], Cc)
+    ws = _ws(nbytes, x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.uf_layernorm_bwd_fused(_ptr(x2), Cc, _ptr(_c(gamma, torch.float32)), _ptr(dy2), Cc, int(dy2.dtype == torch.float32), _ptr(add2), _ptr(dx), Cc,
+                                              _ptr(dg), _ptr(db), B, H, W, Cc, int(windowed), shift, uf_dtype(dy2.dtype), _ptr(ws), nbytes, _stream()),
+                   "uf_layernorm_bwd_fused")
+    return dx, dg, db
+
+
 def linear_wgrad(dy: Tensor, x: Tensor, with_bias: bool = True):
     """nn.Linear parameter gradients from the output gradient dy (..., N) and the layer input x (..., K), same dtype
     (bf16 / f32): returns (dW f32 (N,K), db f32 (N,) or None).  The input gradient is ``linear(dy, W.t())``."""

@@ -192,8 +192,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     g[prefix + "mlp.dwconv.0.weight"] = dw9.t().reshape(4 * C, 1, 3, 3)
     da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
     g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = ops.linear_wgrad(da1, sv["z"])
-    dz = _input_grad(da1, pk.w1_t).float()
-    dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd(sv["x1"], f("norm2.weight"), dz)
+    dz = _input_grad(da1, pk.w1_t)
+    dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W)
     # attention half: proj -> attention -> qkv -> (+modulator) -> partition/roll -> LN1              (model.py:951-986)
     # dx1 += dy (the residual), and the (scaled) gradient entering the attention branch in window order, in one pass
     dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
@@ -208,9 +208,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     dxn = _input_grad(dqkv, pk.wqkv_t)
     if sv["mod"]:                                                           # the (64, C) table is added to every window
         g[prefix + "modulator.weight"] = ops.rows_sum(dxn.reshape(nW, 64 * C)).reshape(64, C)
-    dln = ops.residual_combine(None, dxn, None, B, H, W, windowed=True, shift=shift)  # window_reverse + roll back, to f32
-    dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"] = ops.layernorm_bwd(sv["x2"], f("norm1.weight"), dln)
-    dx = ops.residual_combine(dx, dx1, None, B, H, W, windowed=False)
+    # LN1 backward reads dxn in window order (window_reverse + roll back folded in) and adds the residual path's gradient
+    dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"] = ops.layernorm_bwd_fused(sv["x2"], f("norm1.weight"), dxn, B, H, W, add=dx1, windowed=True, shift=shift)
     return dx.reshape(B, L, C), g
 
 
