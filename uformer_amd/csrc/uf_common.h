@@ -38,12 +38,30 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // half-ulp is 7.8e-3): 16x under the storage rounding; the whole Uformer-B output moves by 5.8e-5 (95.9 dB), measured
 // on the oracle, against 2e-3 / 67 dB for bf16 operands themselves.  The f32 (parity) mode never uses it.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#ifndef UF_GELU_POLY
+#define UF_GELU_POLY 0
+#endif
 __device__ __forceinline__ f32x2_t gelu_bf2(f32x2_t x) {
+#if UF_GELU_POLY
+    // FMA-only form: Phi(x) ~ 0.5 + t P(t^2), t = clamp(x, -4, 4), P of degree 6 (weighted minimax fit of (Phi - 0.5) / x for the
+    // error of x Phi): |GELU error| <= 1.9e-4 evaluated in f32 (the sigmoid form: 4.7e-4), and no transcendental -- v_exp / v_rcp
+    // issue at a quarter of the FMA rate and cannot be packed, the 11 instructions here are 2 v_med3 + 9 packed ops per PAIR.
+    const f32x2_t t = f32x2_t{__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2_t u = t * t;
+    f32x2_t q = u * 2.2783789077607253e-08f + (-1.5987216102075763e-06f);
+    q = q * u + 4.79578593512997e-05f;
+    q = q * u + (-0.0008140378049574792f);
+    q = q * u + 0.00877249427139759f;
+    q = q * u + (-0.06457333266735077f);
+    q = q * u + 0.39788350462913513f;
+    return x * (t * q + 0.5f);
+#else
     constexpr float A = -2.3022081985f;    // -2*sqrt(2/pi)*log2(e)
     constexpr float B = -0.10294324f;      // A * 0.044715
     const f32x2_t u = x * (x * x * B + A);
     const f32x2_t d = f32x2_t{__builtin_amdgcn_exp2f(u[0]), __builtin_amdgcn_exp2f(u[1])} + 1.0f;
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+#endif
 }
 // in-place GELU of N (even) values in the flavour the operand type T calls for
 template <typename T, int N> __device__ __forceinline__ void gelu_n(float* v) {
