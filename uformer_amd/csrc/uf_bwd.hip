@@ -151,10 +151,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // partial in index order (loads of a wave: 32 consecutive columns = 128 B per p), then the 8 lane sums are added in lane order
 // through LDS.  The order depends only on P: bit-reproducible.  (The first version gave every column ONE thread that walked all P
 // partials -- up to 32 K dependent steps on a handful of threads; it was 65 % of the GPU time of a training step.)
-__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n) {
+__device__ __forceinline__ void column_sum_block(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n, int blk) {
     __shared__ float sh[8][33];
     const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
-    const int j = blockIdx.x * 32 + col;
+    const int j = blk * 32 + col;
     float s = 0.f;
     if (j < n) {
         const float* src = partial + j;
@@ -180,6 +180,20 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
         for (int k = 1; k < 8; ++k) t += sh[k][col];
         out[j] = t;
     }
+}
+__global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n) {
+    column_sum_block(partial, P, stride, out, n, blockIdx.x);
+}
+// two independent sums in one launch (weight + bias gradient of a linear layer, dgamma + dbeta of a LayerNorm): these kernels are
+// launch-latency bound (~10 us each, 560 per training step), the arithmetic per output is the same as in the single form
+__global__ __launch_bounds__(256) void column_sum2_kernel(const float* __restrict__ p1, int P1, size_t s1, float* __restrict__ o1, int n1, int nb1,
+                                                          const float* __restrict__ p2, int P2, size_t s2, float* __restrict__ o2, int n2) {
+    if ((int)blockIdx.x < nb1) column_sum_block(p1, P1, s1, o1, n1, blockIdx.x);      // workgroup-uniform branch (the block holds a barrier)
+    else column_sum_block(p2, P2, s2, o2, n2, blockIdx.x - nb1);
+}
+static inline void launch_column_sum2(hipStream_t st, const float* p1, int P1, size_t s1, float* o1, int n1, const float* p2, int P2, size_t s2, float* o2, int n2) {
+    const int nb1 = (n1 + 31) / 32, nb2 = (n2 + 31) / 32;
+    hipLaunchKernelGGL(column_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p1, P1, s1, o1, n1, nb1, p2, P2, s2, o2, n2);
 }
 constexpr int COLSUM_COLS = 32;   // columns per workgroup of column_sum_kernel
 
@@ -264,7 +278,17 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_finalize(const float* __r
     if (j < 10 * C) {
         t = j / C; c = j % C;
         const int cg = c / N, i = c % N;
-        for (long long th = cg + (long long)pl * cv; th < nthreads; th += 8LL * cv) s += partial[(size_t)th * 10 * N + t * N + i];
+        const float* src = partial + t * N + i;
+        const long long step = 8LL * cv;
+        long long th = cg + (long long)pl * cv;
+        for (; th + 7 * step < nthreads; th += 8 * step) {      // eight loads in flight (it was one dependent round trip per partial: 58 us per call)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(th + u * step) * 10 * N];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; th < nthreads; th += step) s += src[(size_t)th * 10 * N];
     }
     sh[pl][col] = s;
     __syncthreads();
@@ -783,8 +807,7 @@ static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const flo
 #undef UF_LNB_CASE
     int rc = check_launch("layernorm_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial, slots, (size_t)2 * C, dgamma, C);
-    hipLaunchKernelGGL(column_sum_kernel, dim3((C + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, partial + C, slots, (size_t)2 * C, dbeta, C);
+    launch_column_sum2(st, partial, slots, (size_t)2 * C, dgamma, C, partial + C, slots, (size_t)2 * C, dbeta, C);
     return check_launch("layernorm_bwd_finalize");
 }
 
@@ -883,8 +906,8 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     int rc = check_launch("linear_wgrad");
     if (rc) return rc;
     const int nk = N * K;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((nk + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
-    if (db) hipLaunchKernelGGL(column_sum_kernel, dim3((N + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_b, S, (size_t)N, db, N);
+    if (db) launch_column_sum2(st, ws_w, S, (size_t)N * K, dW, nk, ws_b, S, (size_t)N, db, N);
+    else hipLaunchKernelGGL(column_sum_kernel, dim3((nk + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
     return check_launch("linear_wgrad_finalize");
 }
 
@@ -1445,7 +1468,6 @@ extern "C" int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const
     }
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
     const int nw = Cin * Cout * 9;
-    hipLaunchKernelGGL(column_sum_kernel, dim3((nw + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)part, P, (size_t)E, dW, nw);
-    hipLaunchKernelGGL(column_sum_kernel, dim3((Cout + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)part + nw, P, (size_t)E, db, Cout);
+    launch_column_sum2(st, (const float*)part, P, (size_t)E, dW, nw, (const float*)part + nw, P, (size_t)E, db, Cout);
     return check_launch("conv3x3_wgrad_finalize");
 }
