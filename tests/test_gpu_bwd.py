@@ -485,7 +485,7 @@ def test_native_block_pack_equals_the_aten_packing(dtype):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("C,shift", [(32, 0), (64, 4), (256, 4), (512, 0)])
 def test_layernorm_bwd_fused_reads_window_order_and_adds_residual(dtype, C, shift):
-    """uf_layernorm_bwd_fused == cast + window_reverse + uf_layernorm_bwd + add: dx bit-identical; dgamma / dbeta sum the rows in window
+    """uf_layernorm_bwd_fused == cast + window_reverse + uf_layernorm_bwd + add: dx to rounding (fma); dgamma / dbeta sum the rows in window
     order instead of raster order (rounding-level difference)."""
     from uformer_amd import ops
     B, H, W = 2, 16, 24
@@ -497,7 +497,7 @@ def test_layernorm_bwd_fused_reads_window_order_and_adds_residual(dtype, C, shif
     dy_raster = ops.window_reverse(dyw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float()
     dx0, dg0, db0 = ops.layernorm_bwd(x, gamma, dy_raster)
     dx, dg, db = ops.layernorm_bwd_fused(x, gamma, dyw, B, H, W, add=add, windowed=True, shift=shift)
-    assert torch.equal(dx, dx0 + add)
+    assert rel(dx, (dx0 + add).cpu()) < 1e-6                                    # the kernel adds the residual gradient with one fma
     assert rel(dg, dg0.cpu()) < 1e-5 and rel(db, db0.cpu()) < 1e-5
     dx1, dg1, db1 = ops.layernorm_bwd_fused(x, gamma, dy_raster.to(dtype), B, H, W)    # raster order, no add: the plain form on T-typed dy
     dx2, dg2, db2 = ops.layernorm_bwd(x, gamma, dy_raster.to(dtype).float())

@@ -101,12 +101,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const bool live = m < rows;
         const int mc = live ? m : rows - 1;                        // clamped: loads stay unconditional
         const int tok = win_h > 0 ? window_row_to_token(mc, win_h, win_w, shift) : mc;
-        f32x4 v[V4], d[V4];
+        f32x4 v[V4], d[V4], ad[V4];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < V4; ++i) {
             v[i] = *reinterpret_cast<const f32x4*>(x + (size_t)tok * ld_x + (i * LPR + sub) * 4);
             d[i] = load_dy4<TD>(dy + (size_t)mc * ld_dy + (i * LPR + sub) * 4);
+            // the residual-path gradient is requested with the row, not where it is added (a dependent round trip per row block)
+            ad[i] = add ? *reinterpret_cast<const f32x4*>(add + (size_t)tok * ld_dx + (i * LPR + sub) * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
         const float mean = allreduce<RedSum, LPR>(sum) * (1.0f / C);
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 f32x4 r = (d[i] * gm[i] - s1 - v[i] * s2) * rstd;
-                if (add) r = r + *reinterpret_cast<const f32x4*>(add + (size_t)tok * ld_dx + (i * LPR + sub) * 4);
+                if (add) r = r + ad[i];
                 *reinterpret_cast<f32x4*>(dx + (size_t)tok * ld_dx + (i * LPR + sub) * 4) = r;
                 adg[i] += d[i] * v[i];
                 adb[i] += d[i];

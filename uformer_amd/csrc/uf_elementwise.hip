@@ -147,6 +147,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
             acc[r][i] = bv[0]; acc[r][i + 1] = bv[1]; acc[r][i + 2] = bv[2]; acc[r][i + 3] = bv[3];
         }
     const T* xb = x + (size_t)b * H * W * C + c;
+    float auxf[ACT == 3 ? DW_R : 1][N];     // ACT 3: the pre-activations of this thread's outputs, requested before the tap loop
+    if constexpr (ACT == 3) {
+#pragma unroll
+        for (int r = 0; r < DW_R; ++r) Vec16<T>::load(aux + ((size_t)(b * H + y0 + r) * W + xw) * C + c, auxf[r]);
+    }
     // one column tap at a time (not unrolled): fully unrolled, hipcc hoists all 18 loads and 72 tap weights, 208-234 VGPRs = 2
     // waves per SIMD, and the kernel ran at 2 TB/s; with 6 loads in flight per thread it fits 4-5 waves
 #pragma unroll 1
@@ -190,11 +195,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
         const size_t o = ((size_t)(b * H + y0 + r) * W + xw) * C + c;
         if constexpr (ACT == 1) gelu_n<T, N>(acc[r]);
         if constexpr (ACT == 3) {
-            float a[N];
-            Vec16<T>::load(aux + o, a);
             round_to<T, N>(acc[r]);
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
+            for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(auxf[r][i]);
         }
         Vec16<T>::store(out + o, acc[r]);
         if constexpr (ACT == 2) {

@@ -241,6 +241,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 }
             }
         }
+        // E_STORE_T_MUL_DGELU: the pre-activation chunks of ALL copy-out iterations are requested here, unconditionally from clamped
+        // addresses, before the barrier -- inside the guarded loop below each one was a dependent HBM round trip per iteration
+        constexpr int CPR_ = WTN * (int)sizeof(T) / 16, RPI_ = 64 / CPR_, NIT_ = WTM / RPI_;
+        u32x4 auxv[EP == E_STORE_T_MUL_DGELU ? NIT_ : 1];
+        if constexpr (EP == E_STORE_T_MUL_DGELU) {
+#pragma unroll
+            for (int it = 0; it < NIT_; ++it) {
+                int m = mw0 + it * RPI_ + lane / CPR_, n = nw0 + (lane % CPR_) * EPC;
+                m = m < p.M ? m : p.M - 1;
+                n = n < p.N ? n : p.N - EPC;
+                auxv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldo + n);
+            }
+        }
         __syncthreads();
         if (!vwave) {
             constexpr int CPR = WTN * (int)sizeof(T) / 16, RPI = 64 / CPR;
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     if constexpr (EP == E_STORE_T_MUL_DGELU) {      // dy (rounded to T, as a separate pass would read it) * GELU'(a)
                         float f[EPC], a[EPC];
                         unpack_chunk<T>(val, f);
-                        unpack_chunk<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldo + n), a);
+                        unpack_chunk<T>(auxv[it], a);
 #pragma unroll
                         for (int e = 0; e < EPC; ++e) f[e] *= gelu_grad_t<T>(a[e]);
                         *reinterpret_cast<u32x4*>(dst) = pack_chunk<T>(f);
