@@ -88,26 +88,32 @@ template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* f
     else return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
 
+// bias of the 4 output channels starting at n (E_UPSAMPLE: channel n % Cout): requested once per tile column BEFORE the guarded stores
+// (inside them every (i, j) tile paid its own dependent round trip)
+template <int EP>
+__device__ __forceinline__ f32x4 epilogue_bias(const GemmParams& p, int n) {
+    int nc = n < p.N ? n : p.N - 4;
+    if constexpr (EP == E_UPSAMPLE) nc = nc % p.Cout;
+    return *reinterpret_cast<const f32x4*>(p.bias + nc);
+}
+
 template <typename T, int EP>
-__device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x4 acc) {
+__device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x4 acc, f32x4 b) {
     if constexpr (EP == E_RES_WINREV || EP == E_RES) {
         int tok = m;
         if constexpr (EP == E_RES_WINREV) tok = window_row_to_token(m, p.H, p.W_, p.shift);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
         const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + (size_t)tok * p.ldr + n);
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)tok * p.ldo + n) = r + (acc + b);
     } else if constexpr (EP == E_STORE_R) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n) = acc + b;
     } else {  // E_UPSAMPLE: n = (dy*2+dx)*Cout + co ; m = (b, y, x) on the (H, W) input grid
         const int qd = n / p.Cout, co = n - qd * p.Cout;
         const int dy = qd >> 1, dx = qd & 1;
         const int hw = p.H * p.W_;
-        const int b = m / hw, r = m - b * hw;
+        const int bb = m / hw, r = m - bb * hw;
         const int y = r / p.W_, x = r - y * p.W_;
-        const size_t dest = ((size_t)(b * 2 * p.H + 2 * y + dy) * (2 * p.W_) + 2 * x + dx);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(p.bias + co);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + dest * p.ldo + co) = acc + bb;
+        const size_t dest = ((size_t)(bb * 2 * p.H + 2 * y + dy) * (2 * p.W_) + 2 * x + dx);
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + dest * p.ldo + co) = acc + b;
     }
 }
 
@@ -304,13 +310,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             }
         }
     } else {
+        f32x4 bv[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) bv[i] = epilogue_bias<EP>(p, n0 + (wn * TN + i) * 16 + fg * 4);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int n = n0 + (wn * TN + i) * 16 + fg * 4;
 #pragma unroll
             for (int j = 0; j < TM; ++j) {
                 const int m = m0 + (wm * TM + j) * 16 + fr;
-                if (m < p.M && n < p.N) epilogue<T, EP>(p, m, n, acc[i][j]);
+                if (m < p.M && n < p.N) epilogue<T, EP>(p, m, n, acc[i][j], bv[i]);
             }
         }
     }
