@@ -5,7 +5,7 @@
 #include <string>
 #include <vector>
 
-#include "uf_common.h"
+#include "uf_internal.h"
 
 namespace uf {
 
@@ -58,6 +58,57 @@ ScopedTimer::~ScopedTimer() {
     if (idx_ < 0) return;
     std::lock_guard<std::mutex> lk(g_mu);
     if (idx_ < (int)g_recs.size()) hipEventRecord(g_recs[idx_].b, st_);
+}
+
+
+// Extra in-order queues + fork/join events of the multi-stream mode.  A LANE = {side streams, fork event, join events}; a
+// call to uf_uformer_fwd owns one lane exclusively from its first hipEventRecord to its last hipStreamWaitEvent, so two host
+// threads (autograd worker + main thread, or two replicas of a process) driving the same GPU never record or wait on each
+// other's events.  Lanes live in a per-device pool guarded by a mutex and are created on demand (normally: one per device);
+// a lane handed back is reused by the next call -- work already enqueued on its side streams keeps its order (in-order
+// queues), and hipStreamWaitEvent binds to the record that preceded it, so re-recording an event for the next call is safe.
+namespace {
+struct LanePool { std::mutex mu; std::vector<Lane*> idle; };
+LanePool& lane_pool(int dev) {
+    static LanePool pools[64];   // constant-initialised members; each pool is guarded by its own mutex
+    return pools[dev];
+}
+}  // namespace
+// takes an idle lane of the current device (or makes one) and grows it to `want` side streams; nullptr on failure
+Lane* acquire_lane(int want, int* dev_out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    *dev_out = dev;
+    LanePool& pool = lane_pool(dev);
+    Lane* ln = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(pool.mu);
+        if (!pool.idle.empty()) { ln = pool.idle.back(); pool.idle.pop_back(); }
+    }
+    if (!ln) ln = new Lane();
+    bool ok = ln->fork || hipEventCreateWithFlags(&ln->fork, hipEventDisableTiming) == hipSuccess;
+    for (; ok && ln->n < want && ln->n < MAX_SIDE; ++ln->n) {
+        ok = hipStreamCreateWithFlags(&ln->s[ln->n], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&ln->join[ln->n], hipEventDisableTiming) == hipSuccess;
+        if (!ok) break;
+    }
+    if (!ok || ln->n < want) {   // hand it back as it is; the caller reports the failure
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.idle.push_back(ln);
+        return nullptr;
+    }
+    return ln;
+}
+void release_lane(Lane* ln, int dev) {
+    LanePool& pool = lane_pool(dev);
+    std::lock_guard<std::mutex> lk(pool.mu);
+    pool.idle.push_back(ln);
+}
+// the lane's general-purpose events (fork points of the block backward's side stream), created on first use
+bool lane_events(Lane* ln, int want) {
+    for (; ln->n_ev < want && ln->n_ev < MAX_LANE_EVENTS; ++ln->n_ev)
+        if (hipEventCreateWithFlags(&ln->ev[ln->n_ev], hipEventDisableTiming) != hipSuccess) return false;
+    return ln->n_ev >= want;
 }
 
 }  // namespace uf

@@ -34,6 +34,14 @@ struct GemmParams {
 // dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream);
 
+// Side streams.  A LANE = {side streams, fork / join events, general-purpose events}; a call owns one lane exclusively between
+// acquire_lane and release_lane, so concurrent callers on one device never record or wait on each other's events (uf_core.hip).
+constexpr int MAX_SIDE = 7, MAX_LANE_EVENTS = 8;
+struct Lane { hipStream_t s[MAX_SIDE] = {}; hipEvent_t fork = nullptr, join[MAX_SIDE] = {}; int n = 0; hipEvent_t ev[MAX_LANE_EVENTS] = {}; int n_ev = 0; };
+Lane* acquire_lane(int want, int* dev_out);
+void release_lane(Lane* ln, int dev);
+bool lane_events(Lane* ln, int want);
+
 // fused attention half (uf_attnblk.hip)
 void debug_set_tbuf(void* p);
 bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads);

@@ -291,49 +291,6 @@ int forward_one_stream(const uf_model_desc* d, const float* img, float* out, int
     return uf_output_proj_fwd(x, ld, d->out_w, d->out_b, img, out, B, H, W, pl.C[8], d->dd_in == 3 ? 1 : 0, st);
 }
 
-// Extra in-order queues + fork/join events of the multi-stream mode.  A LANE = {side streams, fork event, join events}; a
-// call to uf_uformer_fwd owns one lane exclusively from its first hipEventRecord to its last hipStreamWaitEvent, so two host
-// threads (autograd worker + main thread, or two replicas of a process) driving the same GPU never record or wait on each
-// other's events.  Lanes live in a per-device pool guarded by a mutex and are created on demand (normally: one per device);
-// a lane handed back is reused by the next call -- work already enqueued on its side streams keeps its order (in-order
-// queues), and hipStreamWaitEvent binds to the record that preceded it, so re-recording an event for the next call is safe.
-constexpr int MAX_SIDE = 7;
-struct Lane { hipStream_t s[MAX_SIDE] = {}; hipEvent_t fork = nullptr, join[MAX_SIDE] = {}; int n = 0; };
-struct LanePool { std::mutex mu; std::vector<Lane*> idle; };
-LanePool& lane_pool(int dev) {
-    static LanePool pools[64];   // constant-initialised members; each pool is guarded by its own mutex
-    return pools[dev];
-}
-// takes an idle lane of the current device (or makes one) and grows it to `want` side streams; nullptr on failure
-Lane* acquire_lane(int want, int* dev_out) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    *dev_out = dev;
-    LanePool& pool = lane_pool(dev);
-    Lane* ln = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(pool.mu);
-        if (!pool.idle.empty()) { ln = pool.idle.back(); pool.idle.pop_back(); }
-    }
-    if (!ln) ln = new Lane();
-    bool ok = ln->fork || hipEventCreateWithFlags(&ln->fork, hipEventDisableTiming) == hipSuccess;
-    for (; ok && ln->n < want && ln->n < MAX_SIDE; ++ln->n) {
-        ok = hipStreamCreateWithFlags(&ln->s[ln->n], hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&ln->join[ln->n], hipEventDisableTiming) == hipSuccess;
-        if (!ok) break;
-    }
-    if (!ok || ln->n < want) {   // hand it back as it is; the caller reports the failure
-        std::lock_guard<std::mutex> lk(pool.mu);
-        pool.idle.push_back(ln);
-        return nullptr;
-    }
-    return ln;
-}
-void release_lane(Lane* ln, int dev) {
-    LanePool& pool = lane_pool(dev);
-    std::lock_guard<std::mutex> lk(pool.mu);
-    pool.idle.push_back(ln);
-}
 }  // namespace
 
 // Images never interact (LN per token, attention per window, convolutions per image), so the batch can be cut into

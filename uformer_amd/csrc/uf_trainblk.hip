@@ -11,6 +11,8 @@
 // allocated, nothing syncs, every launch goes to the caller's stream.  Parameter gradients are OVERWRITTEN, in the layouts of
 // the reference's parameters (uf_block_grads).  Sums over tokens are the two-stage fixed-order reductions of the op kernels, so a
 // block's gradients are bit-reproducible run to run.
+#include <stdlib.h>
+
 #include "uf_internal.h"
 
 namespace uf {
@@ -27,29 +29,33 @@ struct Bump {
 };
 
 struct BlockPlan {
-    // recomputed forward tensors (T = operand type; f32 where noted)
-    void *xn, *q, *k, *vt, *o, *tA, *tB;      // tA: yw -> dyT -> dyw -> dxn;  tB: z -> dzT -> dO      (each T[M][C])
-    void *a1, *h1, *c, *g2, *dc;              // T[M][4C]; g2 is reused for da1
+    // recomputed forward tensors and backward operands (T = operand type; f32 where noted).  Nothing the weight-gradient jobs read
+    // is overwritten later in the block, so they may run on a side stream while the data-gradient chain goes on.
+    void *xn, *q, *k, *vt, *o;                // T[M][C] (q, k, vt per head)
+    void *tA, *dyw, *dxn, *z, *tE;            // T[M][C]: tA: yw -> dyT;  tE: dz -> dO
+    void *a1, *h1, *c, *g2, *dc, *da1;        // T[M][4C]
     void* dqkv;                               // T[M][3C]
     float *x1, *fB;                           // f32[M][C]: x1;  fB: dx1ln -> dx1 (in place)
     float *dbias, *dw9, *zero;                // f32[heads*4096], f32[9][4C] tap-major dwconv gradient, f32[4C] zeros (bias of the input-gradient GEMMs)
-    void* scratch; size_t scratch_bytes;      // workspace of the op kernels (max over them)
+    void *scratch, *scratch_w; size_t scratch_bytes, scratch_w_bytes;   // workspaces of the op kernels: data-gradient chain / weight-gradient jobs
     size_t total;
 };
 
-size_t op_scratch_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype) {
+void op_scratch_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype, size_t* main_bytes, size_t* side_bytes) {
     const int M = B * H * W;
     size_t s = 0;
     auto mx = [&](size_t v) { if (v > s) s = v; };
+    mx(uf_layernorm_bwd_workspace_bytes(M, C));
+    mx(uf_window_attention_bwd_workspace_bytes(M / 64, heads));
+    *main_bytes = s;
+    s = 0;
     mx(uf_linear_wgrad_workspace_bytes(M, C, 4 * C));
     mx(uf_linear_wgrad_workspace_bytes(M, 4 * C, C));
     mx(uf_linear_wgrad_workspace_bytes(M, C, C));
     mx(uf_linear_wgrad_workspace_bytes(M, 3 * C, C));
-    mx(uf_layernorm_bwd_workspace_bytes(M, C));
-    mx(uf_window_attention_bwd_workspace_bytes(M / 64, heads));
     mx(uf_dwconv3x3_wgrad_workspace_bytes(4 * C, dtype));
     mx(uf_rows_sum_workspace_bytes(M / 64, 64 * C));
-    return s;
+    *side_bytes = s;
 }
 
 BlockPlan plan_block(void* ws, int B, int H, int W, int C, int heads, uf_dtype dtype) {
@@ -57,19 +63,48 @@ BlockPlan plan_block(void* ws, int B, int H, int W, int C, int heads, uf_dtype d
     Bump b{(char*)ws, 0};
     BlockPlan p{};
     p.xn = b.take<void>(M * C * sz);  p.q = b.take<void>(M * C * sz);  p.k = b.take<void>(M * C * sz);  p.vt = b.take<void>(M * C * sz);
-    p.o = b.take<void>(M * C * sz);   p.tA = b.take<void>(M * C * sz); p.tB = b.take<void>(M * C * sz);
+    p.o = b.take<void>(M * C * sz);
+    p.tA = b.take<void>(M * C * sz);  p.dyw = b.take<void>(M * C * sz); p.dxn = b.take<void>(M * C * sz); p.z = b.take<void>(M * C * sz); p.tE = b.take<void>(M * C * sz);
     p.a1 = b.take<void>(M * 4 * C * sz); p.h1 = b.take<void>(M * 4 * C * sz); p.c = b.take<void>(M * 4 * C * sz);
-    p.g2 = b.take<void>(M * 4 * C * sz); p.dc = b.take<void>(M * 4 * C * sz);
+    p.g2 = b.take<void>(M * 4 * C * sz); p.dc = b.take<void>(M * 4 * C * sz); p.da1 = b.take<void>(M * 4 * C * sz);
     p.dqkv = b.take<void>(M * 3 * C * sz);
     p.x1 = b.take<float>(M * C * 4); p.fB = b.take<float>(M * C * 4);
     p.dbias = b.take<float>((size_t)heads * 4096 * 4);
     p.dw9 = b.take<float>((size_t)9 * 4 * C * 4);
     p.zero = b.take<float>((size_t)4 * C * 4);
-    p.scratch_bytes = op_scratch_bytes(B, H, W, C, heads, dtype);
+    op_scratch_bytes(B, H, W, C, heads, dtype, &p.scratch_bytes, &p.scratch_w_bytes);
     p.scratch = b.take<void>(p.scratch_bytes);
+    p.scratch_w = b.take<void>(p.scratch_w_bytes);
     p.total = align_up(b.off, 256);
     return p;
 }
+
+// Two in-order queues of one block backward.  `main` = the caller's stream: recomputation and the data-gradient chain (every kernel
+// the next one waits for).  `side` = a stream of the device's lane pool for the WEIGHT-gradient jobs (token-split GEMMs and their
+// second stages, depthwise-tap gradient, modulator / bias-table sums): nothing downstream reads their results, so they fill the
+// gaps of the chain instead of lengthening it.  A job is forked after the kernel that produces its last operand (event recorded on
+// main, waited on by side); the block joins side back into main before it returns (the next block reuses the workspace).
+// side == main (UF_BWD_STREAMS=1, the two half entry points, or no lane available): plain in-order execution, same results.
+struct Queues {
+    void* main; void* side; Lane* ln; int next_ev;
+    int fork() {                                     // side waits for everything enqueued on main so far
+        if (side == main) return UF_OK;
+        hipEvent_t e = ln->ev[next_ev++ % MAX_LANE_EVENTS];
+        if (hipEventRecord(e, (hipStream_t)main) != hipSuccess || hipStreamWaitEvent((hipStream_t)side, e, 0) != hipSuccess) {
+            set_error("block backward: event record / wait failed");
+            return UF_ERR_LAUNCH;
+        }
+        return UF_OK;
+    }
+    int join() {                                     // main waits for everything enqueued on side so far
+        if (side == main) return UF_OK;
+        if (hipEventRecord(ln->join[0], (hipStream_t)side) != hipSuccess || hipStreamWaitEvent((hipStream_t)main, ln->join[0], 0) != hipSuccess) {
+            set_error("block backward: event record / wait failed");
+            return UF_ERR_LAUNCH;
+        }
+        return UF_OK;
+    }
+};
 
 // (9, N) tap-major -> (N, 9): the layout of mlp.dwconv.0.weight (4C,1,3,3)
 __global__ __launch_bounds__(256) void taps_to_param_kernel(const float* __restrict__ dw9, float* __restrict__ out, int N) {
@@ -114,8 +149,8 @@ int recompute_attn(const uf_block_train_params* p, const BlockPlan& pl, const fl
 // LeFF half up to the second GELU (linear2's output is not needed by the backward): z, a1, h1, c, g2
 int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, int B, int H, int W, int C, uf_dtype dtype, void* st) {
     const int M = B * H * W;
-    UF_TRY(uf_layernorm_fwd(x1, C, p->norm2_w, p->norm2_b, nullptr, pl.tB, B, H, W, C, 0, 0, dtype, st));
-    UF_TRY(uf_linear_pre_gelu_fwd(pl.tB, p->w1, p->b1, pl.a1, pl.h1, M, 4 * C, C, dtype, st));
+    UF_TRY(uf_layernorm_fwd(x1, C, p->norm2_w, p->norm2_b, nullptr, pl.z, B, H, W, C, 0, 0, dtype, st));
+    UF_TRY(uf_linear_pre_gelu_fwd(pl.z, p->w1, p->b1, pl.a1, pl.h1, M, 4 * C, C, dtype, st));
     UF_TRY(uf_dwconv3x3_pre_gelu_fwd(pl.h1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
     return UF_OK;
 }
@@ -123,40 +158,48 @@ int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const fl
 // ---- backward --------------------------------------------------------------------------------------------------------------
 // LeFF half: dy -> fB = LN2-path gradient wrt x1 (WITHOUT the residual dy), parameter gradients.
 int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, const float* dy, const float* drop_leff, const uf_block_grads* g,
-                  int B, int H, int W, int C, uf_dtype dtype, void* st) {
+                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs) {
     const int M = B * H * W, C4 = 4 * C;
+    void *st = qs.main, *sw = qs.side;
     UF_TRY(uf_grad_fork(dy, nullptr, nullptr, pl.tA, drop_leff, B, H, W, C, 0, 0, dtype, st));                          // dyT = T(dy * drop)
-    UF_TRY(uf_linear_wgrad(pl.tA, C, pl.g2, C4, g->w2, g->b2, M, C, C4, dtype, pl.scratch, pl.scratch_bytes, st));
+    UF_TRY(qs.fork());
+    UF_TRY(uf_linear_wgrad(pl.tA, C, pl.g2, C4, g->w2, g->b2, M, C, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_mul_dgelu(pl.tA, p->w2_t, pl.zero, pl.c, pl.dc, M, C4, C, dtype, st));                               // dc = (dyT W2) GELU'(c)
-    UF_TRY(uf_dwconv3x3_wgrad(pl.h1, pl.dc, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch, pl.scratch_bytes, st));
-    hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)pl.dw9, g->wdw, C4);
+    UF_TRY(qs.fork());
+    UF_TRY(uf_dwconv3x3_wgrad(pl.h1, pl.dc, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
+    hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)sw, (const float*)pl.dw9, g->wdw, C4);
     UF_TRY(check_launch("taps_to_param"));
-    UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.g2, B, H, W, C4, dtype, st));                             // da1 (over g2)
-    UF_TRY(uf_linear_wgrad(pl.g2, C4, pl.tB, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch, pl.scratch_bytes, st));       // tB still holds z
-    UF_TRY(uf_linear_fwd(pl.g2, p->w1_t, pl.zero, pl.tB, M, C, C4, 0, dtype, st));                                         // dz (over z)
-    UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tB, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
+    UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.da1, B, H, W, C4, dtype, st));                            // da1
+    UF_TRY(qs.fork());
+    UF_TRY(uf_linear_wgrad(pl.da1, C4, pl.z, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
+    UF_TRY(uf_linear_fwd(pl.da1, p->w1_t, pl.zero, pl.tE, M, C, C4, 0, dtype, st));                                        // dz
+    UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tE, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
     return UF_OK;
 }
 
-// attention half: tA = T(dx1 * drop) in window order (already there), recomputed xn, q, k, vt, o -> dx = LN1-path gradient (+ dx1 when
-// add_dx1), parameter gradients.
+// attention half: dyw = T(dx1 * drop) in window order (already there), recomputed xn, q, k, vt, o -> dx = LN1-path gradient + dx1,
+// parameter gradients.
 int backward_attn(const uf_block_train_params* p, const BlockPlan& pl, const float* x, const float* dx1, float* dx, const uf_block_grads* g,
-                  int B, int H, int W, int C, uf_dtype dtype, void* st) {
+                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs) {
     const int M = B * H * W;
-    UF_TRY(uf_linear_wgrad(pl.tA, C, pl.o, C, g->wproj, g->bproj, M, C, C, dtype, pl.scratch, pl.scratch_bytes, st));
-    UF_TRY(uf_linear_fwd(pl.tA, p->wproj_t, pl.zero, pl.tB, M, C, C, 0, dtype, st));                                       // dO
-    UF_TRY(uf_window_attention_bwd_qkv(pl.q, pl.k, pl.vt, p->rpb_dense, nullptr, 0, pl.tB, C, pl.dqkv, pl.dbias, M / 64, p->heads, 32, H, W, p->shift, dtype,
+    void *st = qs.main, *sw = qs.side;
+    UF_TRY(qs.fork());                                                                                                     // dyw is ready
+    UF_TRY(uf_linear_wgrad(pl.dyw, C, pl.o, C, g->wproj, g->bproj, M, C, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
+    UF_TRY(uf_linear_fwd(pl.dyw, p->wproj_t, pl.zero, pl.tE, M, C, C, 0, dtype, st));                                      // dO
+    UF_TRY(uf_window_attention_bwd_qkv(pl.q, pl.k, pl.vt, p->rpb_dense, nullptr, 0, pl.tE, C, pl.dqkv, pl.dbias, M / 64, p->heads, 32, H, W, p->shift, dtype,
                                        pl.scratch, pl.scratch_bytes, st));
-    UF_TRY(uf_rpb_table_grad(pl.dbias, g->rpb_table, p->heads, st));
-    UF_TRY(uf_linear_wgrad(pl.dqkv, 3 * C, pl.xn, C, g->wqkv, g->bqkv, M, 3 * C, C, dtype, pl.scratch, pl.scratch_bytes, st));
-    UF_TRY(uf_linear_fwd(pl.dqkv, p->wqkv_t, pl.zero, pl.tA, M, C, 3 * C, 0, dtype, st));                                  // dxn (window order)
+    UF_TRY(qs.fork());
+    UF_TRY(uf_rpb_table_grad(pl.dbias, g->rpb_table, p->heads, sw));
+    UF_TRY(uf_linear_wgrad(pl.dqkv, 3 * C, pl.xn, C, g->wqkv, g->bqkv, M, 3 * C, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
+    UF_TRY(uf_linear_fwd(pl.dqkv, p->wqkv_t, pl.zero, pl.dxn, M, C, 3 * C, 0, dtype, st));                                 // dxn (window order)
     if (p->modulator) {
         UF_REQUIRE(g->modulator, UF_ERR_NULL, "block backward: the block has a modulator but grads->modulator is NULL");
-        UF_TRY(uf_rows_sum(pl.tA, 64 * C, g->modulator, M / 64, 64 * C, dtype, pl.scratch, pl.scratch_bytes, st));
+        UF_TRY(qs.fork());
+        UF_TRY(uf_rows_sum(pl.dxn, 64 * C, g->modulator, M / 64, 64 * C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     }
     // LN1 backward reads dxn in window order (window_reverse + roll back folded in) and adds the residual path's gradient
-    UF_TRY(uf_layernorm_bwd_fused(x, C, p->norm1_w, pl.tA, C, 0, dx1, dx, C, g->norm1_w, g->norm1_b, B, H, W, C, 1, p->shift, dtype, pl.scratch, pl.scratch_bytes, st));
-    return UF_OK;
+    UF_TRY(uf_layernorm_bwd_fused(x, C, p->norm1_w, pl.dxn, C, 0, dx1, dx, C, g->norm1_w, g->norm1_b, B, H, W, C, 1, p->shift, dtype, pl.scratch, pl.scratch_bytes, st));
+    return qs.join();
 }
 
 int zero_bias(const BlockPlan& pl, int C, void* st) {
@@ -175,18 +218,25 @@ extern "C" size_t uf_lewin_block_bwd_workspace_bytes(int B, int H, int W, int C,
     return plan_block(nullptr, B, H, W, C, heads, dtype).total;
 }
 
+static int bwd_streams() { static const int v = getenv("UF_BWD_STREAMS") ? atoi(getenv("UF_BWD_STREAMS")) : 2; return v; }
+
 extern "C" int uf_lewin_block_bwd(const uf_block_train_params* p, const float* x, const float* dy, float* dx, const float* drop_attn, const float* drop_leff,
                                   const uf_block_grads* g, int B, int H, int W, int C, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_TRY(check_common("uf_lewin_block_bwd", p, g, B, H, W, C, dtype, ws, ws_bytes));
     UF_REQUIRE(x && dy && dx, UF_ERR_NULL, "uf_lewin_block_bwd: null pointer");
     const BlockPlan pl = plan_block(ws, B, H, W, C, p->heads, dtype);
+    Queues qs{stream, stream, nullptr, 0};
+    int dev = 0;
+    Lane* ln = bwd_streams() >= 2 ? acquire_lane(1, &dev) : nullptr;                 // no lane: everything on the caller's stream
+    struct Guard { Lane* l; int d; ~Guard() { if (l) release_lane(l, d); } } guard{ln, dev};
+    if (ln && lane_events(ln, MAX_LANE_EVENTS)) { qs.side = ln->s[0]; qs.ln = ln; }
     UF_TRY(zero_bias(pl, C, stream));
     UF_TRY(recompute_attn(p, pl, x, drop_attn, true, B, H, W, C, dtype, stream));
     UF_TRY(recompute_leff(p, pl, pl.x1, B, H, W, C, dtype, stream));
-    UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, stream));
-    // dx1 = LN2-path gradient + dy (in place over fB), and T(dx1 * drop_attn) in window order -> tA, one pass
-    UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.tA, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
-    return backward_attn(p, pl, x, pl.fB, dx, g, B, H, W, C, dtype, stream);
+    UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
+    // dx1 = LN2-path gradient + dy (in place over fB), and T(dx1 * drop_attn) in window order -> dyw, one pass
+    UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
+    return backward_attn(p, pl, x, pl.fB, dx, g, B, H, W, C, dtype, qs);
 }
 
 extern "C" int uf_leff_bwd(const uf_block_train_params* p, const float* x1, const float* dy, float* dx1, const float* drop_leff, const uf_block_grads* g,
@@ -194,9 +244,10 @@ extern "C" int uf_leff_bwd(const uf_block_train_params* p, const float* x1, cons
     UF_TRY(check_common("uf_leff_bwd", p, g, B, H, W, C, dtype, ws, ws_bytes));
     UF_REQUIRE(x1 && dy && dx1, UF_ERR_NULL, "uf_leff_bwd: null pointer");
     const BlockPlan pl = plan_block(ws, B, H, W, C, p->heads, dtype);
+    Queues qs{stream, stream, nullptr, 0};
     UF_TRY(zero_bias(pl, C, stream));
     UF_TRY(recompute_leff(p, pl, x1, B, H, W, C, dtype, stream));
-    UF_TRY(backward_leff(p, pl, x1, dy, drop_leff, g, B, H, W, C, dtype, stream));
+    UF_TRY(backward_leff(p, pl, x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
     return uf_residual_combine(pl.fB, dy, 1, dx1, nullptr, B, H, W, C, 0, 0, dtype, stream);                               // + the residual path
 }
 
@@ -205,10 +256,11 @@ extern "C" int uf_lewin_attn_bwd(const uf_block_train_params* p, const float* x,
     UF_TRY(check_common("uf_lewin_attn_bwd", p, g, B, H, W, C, dtype, ws, ws_bytes));
     UF_REQUIRE(x && dx1 && dx, UF_ERR_NULL, "uf_lewin_attn_bwd: null pointer");
     const BlockPlan pl = plan_block(ws, B, H, W, C, p->heads, dtype);
+    Queues qs{stream, stream, nullptr, 0};
     UF_TRY(zero_bias(pl, C, stream));
     UF_TRY(recompute_attn(p, pl, x, drop_attn, false, B, H, W, C, dtype, stream));
-    UF_TRY(uf_grad_fork(dx1, nullptr, nullptr, pl.tA, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
-    return backward_attn(p, pl, x, dx1, dx, g, B, H, W, C, dtype, stream);
+    UF_TRY(uf_grad_fork(dx1, nullptr, nullptr, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
+    return backward_attn(p, pl, x, dx1, dx, g, B, H, W, C, dtype, qs);
 }
 
 // ---- samplers --------------------------------------------------------------------------------------------------------------
