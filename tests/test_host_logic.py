@@ -135,3 +135,40 @@ def test_fragment_major_packing_formula_cpu():
             assert tab[1, ys[q] - ys[k] + 7, 7 - (xs[q] - xs[k])] == dense[1, q, k]
     broken = dense.clone(); broken[0, 3, 5] += 1.0
     assert packing.pack_rpb_table(broken) is None
+
+
+def test_block_gradient_buffer_covers_every_parameter_of_every_block():
+    """ops._block_grads lays the uf_block_grads outputs out in one flat buffer; train._named_block_grads maps them onto the
+    reference's parameter names: for every LeWin block of Uformer-B the names and shapes must be exactly the block's float
+    parameters (the fused q|k|v gradient split into to_q / to_kv), every piece 256-byte aligned."""
+    import torch
+    from uformer_amd import ops, spec, train
+    cfg = spec.arch_config("Uformer_B", 128)
+    shapes = {k: tuple(shape) for k, shape, kind in spec.state_dict_spec(cfg) if kind != "rpi"}
+    dims = [cfg.embed_dim * m for m in (1, 2, 4, 8, 16, 16, 8, 4, 2)]
+    seen = set()
+    for s, stage in enumerate(spec.STAGES):
+        C, heads = dims[s], cfg.num_heads[s]
+        for b in range(cfg.depths[s]):
+            prefix = f"{stage}.blocks.{b}."
+            has_mod = (prefix + "modulator.weight") in shapes
+            flat, g, views = ops._block_grads(C, heads, has_mod, "cpu")
+            assert all(v.data_ptr() % 256 == flat.data_ptr() % 256 for v in views.values())
+            assert (g.modulator is not None) == has_mod
+            named = train._named_block_grads(prefix, views, C)
+            want = {k for k in shapes if k.startswith(prefix)}
+            assert set(named) == want, (prefix, set(named) ^ want)
+            for k, v in named.items():
+                assert tuple(v.shape) == shapes[k], (k, tuple(v.shape), shapes[k])
+            seen |= want
+    rest = {k.split(".")[0] for k in shapes if k not in seen}
+    assert rest == {"input_proj", "output_proj", "dowsample_0", "dowsample_1", "dowsample_2", "dowsample_3", "upsample_0", "upsample_1", "upsample_2", "upsample_3"}
+
+
+def test_relative_position_index_check_accepts_only_the_reference_buffer():
+    import torch
+    from uformer_amd import spec, train
+    idx = spec.relative_position_index(8)
+    assert train._index_is_standard(idx.clone())
+    bad = idx.clone(); bad[3, 5] += 1
+    assert not train._index_is_standard(bad)
