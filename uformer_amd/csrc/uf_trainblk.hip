@@ -230,13 +230,18 @@ extern "C" int uf_lewin_block_bwd(const uf_block_train_params* p, const float* x
     Lane* ln = bwd_streams() >= 2 ? acquire_lane(1, &dev) : nullptr;                 // no lane: everything on the caller's stream
     struct Guard { Lane* l; int d; ~Guard() { if (l) release_lane(l, d); } } guard{ln, dev};
     if (ln && lane_events(ln, MAX_LANE_EVENTS)) { qs.side = ln->s[0]; qs.ln = ln; }
-    UF_TRY(zero_bias(pl, C, stream));
-    UF_TRY(recompute_attn(p, pl, x, drop_attn, true, B, H, W, C, dtype, stream));
-    UF_TRY(recompute_leff(p, pl, pl.x1, B, H, W, C, dtype, stream));
-    UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
-    // dx1 = LN2-path gradient + dy (in place over fB), and T(dx1 * drop_attn) in window order -> dyw, one pass
-    UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
-    return backward_attn(p, pl, x, pl.fB, dx, g, B, H, W, C, dtype, qs);
+    auto run = [&]() -> int {
+        UF_TRY(zero_bias(pl, C, stream));
+        UF_TRY(recompute_attn(p, pl, x, drop_attn, true, B, H, W, C, dtype, stream));
+        UF_TRY(recompute_leff(p, pl, pl.x1, B, H, W, C, dtype, stream));
+        UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
+        // dx1 = LN2-path gradient + dy (in place over fB), and T(dx1 * drop_attn) in window order -> dyw, one pass
+        UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
+        return backward_attn(p, pl, x, pl.fB, dx, g, B, H, W, C, dtype, qs);
+    };
+    const int rc = run();
+    if (rc != UF_OK) (void)qs.join();      // an error half-way: whatever was already forked must still be ordered before the caller reuses the workspace
+    return rc;
 }
 
 extern "C" int uf_leff_bwd(const uf_block_train_params* p, const float* x1, const float* dy, float* dx1, const float* drop_leff, const uf_block_grads* g,
