@@ -10,8 +10,11 @@ data-path collective (weak scaling: per-GPU work is fixed).
 A "step" = one forward of the hot path (Uformer.forward through uf_uformer_fwd) over one batch of
 synthetic images already resident in HBM.  Rank 0 prints ONE JSON line.  Besides the contract
 fields it carries
-  * ``modes``: throughput AND parity of both operand types -- bf16 (the headline) and f32 (exact-f32
-    MFMA, the mode that meets the 1e-3 north-star tolerance), each against the oracle on the same image;
+  * ``modes``: throughput AND parity of every operand type -- bf16 (the headline: BASELINE configs[1] names it), f16 (IEEE
+    half, the reference's own AMP type: same MFMA rate, meets the 1e-3 north-star tolerance) and f32 (exact-f32 MFMA), each
+    against the oracle on the same image; and ``modes.train``: BASELINE configs[2], Uformer-B 256x256 batch 32 forward +
+    backward + Charbonnier + AdamW on the native kernels, with its own ``roofline`` (dominant instrumented backward kernel)
+    and ``cpu_baseline`` (the oracle under torch autograd + torch.optim.AdamW at batch 2 on this host);
   * ``roofline``: the dominant kernel, from HIP events on the launch stream (library instrumentation);
     ``traffic`` (HBM bytes per launch from PMC counters) only when profiles/r02_pmc_traffic.json was
     measured on exactly these kernel sources (stamp check), else null;
@@ -38,7 +41,8 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MFMA peaks (same guide)
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}   # dense MFMA peaks (same guide)
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 MB_PER_IMAGE_B256 = 184.8       # compulsory bf16 activation bytes per image (blocks in+out once, samplers, skips, stem/head)
 MB_WEIGHTS_B = 101.8            # bf16 weights, read once per batch
 
@@ -52,16 +56,20 @@ def kernel_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def kernel_breakdown(model, x, steps):
-    """Per-kernel-class time over `steps` forwards, measured with HIP events on the launch stream
+def kernel_breakdown(model, x, steps, fn=None):
+    """Per-kernel-class time over `steps` forwards (or calls of ``fn``), measured with HIP events on the launch stream
     (library-side instrumentation, uf_timing_enable)."""
     from uformer_amd import _lib
     lib = _lib.load()
     torch.cuda.synchronize()
     lib.uf_timing_enable(1)
-    with torch.no_grad():
+    if fn is not None:
         for _ in range(steps):
-            model(x)
+            fn()
+    else:
+        with torch.no_grad():
+            for _ in range(steps):
+                model(x)
     torch.cuda.synchronize()
     lib.uf_timing_enable(0)
     buf = ctypes.create_string_buffer(1 << 16)
@@ -125,6 +133,113 @@ def cpu_baseline(arch, img, budget_s=28.0):
     return out, (x1, ref)
 
 
+def cpu_train_baseline(arch, img, batch=2, steps=1, warmup=0):
+    """BASELINE configs[2] on the host: the oracle forward under torch autograd + the reference's criterion and optimizer
+    (Charbonnier eps 1e-3, torch.optim.AdamW 2e-4 / 0.02), batch 2.  One step is ~15 s on 8 cores, so the default is ONE timed step
+    without a warm-up step (the forward primitives are warm from cpu_baseline(), which runs first; thread count = its best one)."""
+    from oracle import uformer_oracle as O
+    from uformer_amd import spec
+    cfg = spec.arch_config(arch, img_size=img)
+    sd = spec.synth_state_dict(cfg, 1234)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    x, tgt = spec.synth_input(batch, img, img, 1234), spec.synth_input(batch, img, img, 1235)
+    kw = dict(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    times = []
+    for i in range(steps + warmup):
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        loss = O.charbonnier_loss(O.uformer_forward(x, params, **kw), tgt)
+        loss.backward()
+        opt.step()
+        if i >= warmup:
+            times.append(time.perf_counter() - t0)
+    v = batch / statistics.median(times)
+    return {"value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": (f"oracle forward under torch autograd + Charbonnier + torch.optim.AdamW, {arch} {img}x{img} batch {batch}, fp32: "
+                       f"median of {steps} step(s) after {warmup} warm-up step(s) = {v:.3f} img/s ({sum(times):.0f} s of CPU work)")}
+
+
+def train_mode(args, cfg, sd, dev, ud, dtype_name):
+    """BASELINE configs[2]: forward + backward + Charbonnier + AdamW, batch `--train-batch` per GPU, train() mode (DropPath 0.1),
+    every step on the native kernels (uformer_amd.train / losses / optim).  Returns the ``modes.train`` entry."""
+    from uformer_amd import losses as ul
+    from uformer_amd import model as um
+    from uformer_amd import optim as uo
+    from uformer_amd import spec
+    rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+    torch.manual_seed(1234 + rank)
+    m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
+                   dd_in=cfg.dd_in, compute_dtype=TORCH_DTYPE[dtype_name])
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).train()
+    opt = uo.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77
+    crit = ul.CharbonnierLoss()
+    B = args.train_batch
+    x = spec.synth_input(B, args.img, args.img, 1234 + 2 * rank).to(dev)
+    tgt = spec.synth_input(B, args.img, args.img, 1235 + 2 * rank).to(dev)
+    ls = 65536.0 if dtype_name == "f16" else 1.0
+    world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    sink = ud.OverlappedGradientAllReduce(m) if world > 1 else None
+    m.grad_sink = sink
+    state = {}
+
+    def step():
+        if sink is not None:
+            sink.begin_step()
+        else:
+            opt.zero_grad(set_to_none=True)
+        loss = crit(m(x), tgt)
+        (loss * ls if ls != 1.0 else loss).backward()
+        if sink is not None:
+            sink.finish()
+        opt.step(grad_scale=(sink.grad_scale if sink is not None else 1.0) / ls)
+        state["loss"] = loss
+
+    for _ in range(max(1, args.train_warmup)):
+        step()
+    torch.cuda.synchronize(); ud.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        step()
+    torch.cuda.synchronize(); ud.barrier()
+    dt = ud.max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps
+    flops_img = 3 * 2.0 * m.flops()                        # SURVEY 8d: FLOPs_train = 3 x forward
+    v = world * B / dt
+    out = {"workload": f"{args.arch} {args.img}x{args.img} training step (fwd + bwd + Charbonnier + AdamW), batch {B}/GPU, DropPath 0.1, synthetic data",
+           "images_per_s": v, "ms_per_step": 1e3 * dt, "steps": args.train_steps, "batch_per_gpu": B, "dtype": dtype_name, "loss_scale": ls,
+           "loss": float(state["loss"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
+           "mfma_frac_whole_step": v * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[dtype_name],
+           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}
+    if rank == 0:
+        rows = kernel_breakdown(None, None, 1, fn=step)
+        sym = {}
+        for r in rows:
+            a_ = sym.setdefault(r["kernel"].split(" ")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
+            for k_ in ("ms", "launches", "flops", "bytes"):
+                a_[k_] += r[k_]
+        bwd = {k: v_ for k, v_ in sym.items() if "wgrad" in k or "bwd" in k} or sym
+        name, dom = max(bwd.items(), key=lambda kv: kv[1]["ms"])
+        sec = dom["ms"] / 1e3
+        ridge = MFMA_PEAK_TFLOPS[dtype_name] * 1e12 / (HBM_PEAK_GBS * 1e9)
+        if dom["bytes"] > 0 and dom["flops"] / dom["bytes"] < ridge:
+            ach = dom["bytes"] / sec / 1e9
+            rf = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}
+        else:
+            ach = dom["flops"] / sec / 1e12
+            rf = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dtype_name], "traffic": None}
+        rf.update({"kernel": name, "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
+                   "achieved_tflops": dom["flops"] / sec / 1e12, "achieved_gbs": dom["bytes"] / sec / 1e9,
+                   "note": "dominant instrumented backward kernel of one training step (HIP events on the launch stream; the step runs single-stream while instrumented)",
+                   "instrumented_gpu_ms_per_step": sum(v_["ms"] for v_ in sym.values())})
+        out["roofline"] = rf
+        out["kernels"] = [{"kernel": k_, "ms_per_step": v_["ms"], "launches_per_step": v_["launches"], "tflops": v_["flops"] / max(v_["ms"], 1e-9) / 1e9,
+                           "gbs": v_["bytes"] / max(v_["ms"], 1e-9) / 1e6} for k_, v_ in sorted(sym.items(), key=lambda kv: -kv[1]["ms"])[:12]]
+    del m, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def build_model(args, cfg, sd, dev, cd):
     from uformer_amd import model as um
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
@@ -158,9 +273,15 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--arch", default="Uformer_B")
     ap.add_argument("--img", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-f32-mode", action="store_true", help="skip the second (f32, parity-gate) mode")
+    ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-f32 mode")
+    ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
+    ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
+    ap.add_argument("--train-batch", type=int, default=32)
+    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-warmup", type=int, default=1)
+    ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--error-budget", action="store_true", help="bf16-mode error by source through oracle/bf16_budget.py (about a CPU-minute)")
     ap.add_argument("--kernels-json", default=None, help="also write the per-kernel breakdown to this file")
     args = ap.parse_args()
@@ -173,7 +294,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    cd = TORCH_DTYPE[args.dtype]
 
     cfg = spec.arch_config(args.arch, img_size=args.img)
     sd = spec.synth_state_dict(cfg, 1234)
@@ -184,14 +305,17 @@ def main():
 
     elapsed = timed_steps(model, x, args.steps, args.warmup, ud, dev)
     images = ud.sum_over_ranks(float((b - a) * args.steps), dev)
-    # second mode (the other operand type): fewer steps -- exact-f32 MFMA runs at 1/16 of the bf16 rate
-    other = "f32" if args.dtype == "bf16" else "bf16"
-    model2 = elapsed2 = None
-    steps2 = max(3, args.steps // 4) if other == "f32" else args.steps
-    if not args.no_f32_mode and args.arch == "Uformer_B":
-        model2 = build_model(args, cfg, sd, dev, torch.float32 if other == "f32" else torch.bfloat16)
-        elapsed2 = timed_steps(model2, x, steps2, 2, ud, dev)
-        images2 = ud.sum_over_ranks(float((b - a) * steps2), dev)
+    # the other operand types: same steps for the 2-byte types, fewer for exact-f32 MFMA (1/16 of the bf16 / f16 rate)
+    others = {}
+    if not args.no_other_modes and args.arch == "Uformer_B":
+        for other in [d for d in ("bf16", "f16", "f32") if d != args.dtype and not (d == "f32" and args.no_f32_mode)]:
+            steps2 = max(3, args.steps // 4) if other == "f32" else args.steps
+            m2 = build_model(args, cfg, sd, dev, TORCH_DTYPE[other])
+            e2 = timed_steps(m2, x, steps2, 2, ud, dev)
+            others[other] = (m2, e2, steps2, ud.sum_over_ranks(float((b - a) * steps2), dev))
+    train_entry = None
+    if not args.no_train_mode and args.arch == "Uformer_B":
+        train_entry = train_mode(args, cfg, sd, dev, ud, args.train_dtype)
 
     out = None
     if rank == 0:
@@ -214,10 +338,12 @@ def main():
             out["hbm_frac_whole_model_compulsory"] = value * (MB_PER_IMAGE_B256 + MB_WEIGHTS_B / args.batch) * 1e6 / world / (HBM_PEAK_GBS * 1e9)
         out["modes"] = {args.dtype: {"images_per_s": value, "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps,
                                      "mfma_frac_whole_model": out["mfma_frac_whole_model"]}}
-        if model2 is not None:
-            v2 = images2 / elapsed2
-            out["modes"][other] = {"images_per_s": v2, "ms_per_step": 1e3 * elapsed2 / steps2, "steps": steps2,
+        for other, (m2, e2, steps2, images2) in others.items():
+            v2 = images2 / e2
+            out["modes"][other] = {"images_per_s": v2, "ms_per_step": 1e3 * e2 / steps2, "steps": steps2,
                                    "mfma_frac_whole_model": v2 * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[other]}
+        if train_entry is not None:
+            out["modes"]["train"] = train_entry
         # ---- roofline of the dominant kernel: HIP events on the launch stream, per kernel class ----
         rows = kernel_breakdown(model, x, 3)
         total_ms = sum(r["ms"] for r in rows)
@@ -273,9 +399,7 @@ def main():
             from oracle import uformer_oracle as O
             out["parity"] = {"checked": "1 image, same weights/input as the CPU baseline, vs oracle/uformer_oracle.py (pinned to the reference's fixtures)",
                              "north_star_tolerance_max_abs": 1e-3}
-            for mname, m in ((args.dtype, model), (other, model2)):
-                if m is None:
-                    continue
+            for mname, m in [(args.dtype, model)] + [(o, v_[0]) for o, v_ in others.items()]:
                 with torch.no_grad():
                     y1 = m(x1.to(dev)).float().cpu()
                 d = y1 - ref
@@ -284,13 +408,17 @@ def main():
                 out["modes"][mname].update(out["parity"][mname])
             out["parity"]["max_abs_err_vs_oracle"] = out["parity"][args.dtype]["max_abs_err_vs_oracle"]
             out["parity"]["psnr_db_vs_oracle"] = out["parity"][args.dtype]["psnr_db_vs_oracle"]
+            if train_entry is not None:
+                train_entry["cpu_baseline"] = cpu_train_baseline(args.arch, args.img)
             if args.error_budget:
                 from oracle import bf16_budget as BB
                 from uformer_amd import spec as sp
                 c2 = sp.arch_config(args.arch, img_size=args.img)
-                out["parity"]["error_budget_bf16"] = {
-                    "method": "oracle/bf16_budget.py: the f32 oracle with ONE rounding point / approximation of the bf16 kernels switched on at a time",
-                    "by_source": BB.error_budget(x1, sd, ref, img_size=c2.img_size, embed_dim=c2.embed_dim, depths=c2.depths, num_heads=c2.num_heads, dd_in=c2.dd_in)}
+                for op_ in ("bf16", "f16"):
+                    out["parity"]["error_budget_" + op_] = {
+                        "method": f"oracle/bf16_budget.py (operand={op_}): the f32 oracle with ONE rounding point / approximation of the {op_} kernels switched on at a time",
+                        "by_source": BB.error_budget(x1, sd, ref, img_size=c2.img_size, embed_dim=c2.embed_dim, depths=c2.depths, num_heads=c2.num_heads, dd_in=c2.dd_in,
+                                                     operand=op_)}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

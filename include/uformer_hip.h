@@ -13,7 +13,9 @@
  *     Nothing throws or aborts across this boundary.
  *   - tokens are channel-last:  x[b][h][w][c]  ==  the reference's (B, L=H*W, C) layout.
  *   - `dtype` (uf_dtype) is the type T of GEMM operands and of intermediate activations
- *     (UF_F32: exact-f32 MFMA, the 1e-3 parity mode; UF_BF16: bf16 operands, f32 accumulate).
+ *     (UF_F32: exact-f32 MFMA; UF_BF16: bf16 operands, f32 accumulate; UF_F16: IEEE half operands, f32
+ *     accumulate -- the reference's own reduced-precision mode (torch.cuda.amp autocast is fp16,
+ *     train/train_denoise.py:164,180-184): the full-speed mode that meets the 1e-3 output tolerance).
  *     The residual stream, LayerNorm/softmax/GELU math, biases and all small tables are f32.
  *   - residual-stream tensors carry a row stride `ld` (elements) so that an encoder stage can
  *     live inside the second half of a decoder concat buffer (model.py:1288 torch.cat).
@@ -31,7 +33,7 @@ extern "C" {
 
 #define UF_ABI_VERSION 1
 
-typedef enum { UF_F32 = 0, UF_BF16 = 1 } uf_dtype;
+typedef enum { UF_F32 = 0, UF_BF16 = 1, UF_F16 = 2 } uf_dtype;
 
 #define UF_OK 0
 #define UF_ERR_SHAPE (-1)

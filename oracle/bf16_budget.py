@@ -1,4 +1,4 @@
-"""Error budget of the bf16 mode, by source.  TEST / ANALYSIS INFRASTRUCTURE ONLY (same rules as uformer_oracle.py).
+"""Error budget of the 2-byte operand modes (bf16, and f16 = the reference's own AMP type), by source.  TEST / ANALYSIS INFRASTRUCTURE ONLY (same rules as uformer_oracle.py).
 
 The HIP bf16 path rounds to bf16 at a fixed set of points and uses two approximations; this file restates the forward of
 uformer_oracle.py with each of those as a SWITCH, so that ``bench.py --error-budget`` (and tests/test_host_logic.py) can turn
@@ -35,6 +35,14 @@ def bf(x: Tensor) -> Tensor:
     return x.to(torch.bfloat16).to(torch.float32)
 
 
+def hf(x: Tensor) -> Tensor:
+    """IEEE half rounding (round to nearest even, gradual underflow, saturation to inf above 65504: as v_cvt_f16_f32)."""
+    return x.to(torch.float16).to(torch.float32)
+
+
+ROUND = {"bf16": bf, "f16": hf}
+
+
 def gelu_sigmoid(x: Tensor) -> Tensor:
     a = -2.3022081985
     b = -0.10294324
@@ -42,14 +50,15 @@ def gelu_sigmoid(x: Tensor) -> Tensor:
 
 
 class Budget:
-    def __init__(self, on: Iterable[str]):
+    def __init__(self, on: Iterable[str], operand: str = "bf16"):
+        self.rnd = ROUND[operand]
         self.on: FrozenSet[str] = frozenset(on)
         bad = self.on - set(ALL)
         if bad:
             raise ValueError(f"unknown switches {sorted(bad)}")
 
     def r(self, name: str, x: Tensor) -> Tensor:
-        return bf(x) if name in self.on else x
+        return self.rnd(x) if name in self.on else x
 
     def gelu(self, x: Tensor) -> Tensor:
         return gelu_sigmoid(x) if "gelu" in self.on else O.gelu_erf(x)
@@ -126,9 +135,10 @@ def _up(x: Tensor, p: Dict[str, Tensor], prefix: str, q: Budget) -> Tensor:
 
 @torch.no_grad()
 def forward(x: Tensor, p: Dict[str, Tensor], switches: Iterable[str], *, img_size: int, embed_dim: int, depths: Sequence[int],
-            num_heads: Sequence[int], dd_in: int = 3) -> Tensor:
-    """uformer_oracle.uformer_forward with the roundings / approximations named in ``switches`` applied (eval mode, no mask)."""
-    q = Budget(switches)
+            num_heads: Sequence[int], dd_in: int = 3, operand: str = "bf16") -> Tensor:
+    """uformer_oracle.uformer_forward with the roundings / approximations named in ``switches`` applied (eval mode, no mask);
+    ``operand`` = the 2-byte type the rounding points use ("bf16" or "f16")."""
+    q = Budget(switches, operand)
     shifts = O.block_shifts(img_size, depths)
 
     def stage(y: Tensor, s: int) -> Tensor:

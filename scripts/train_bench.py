@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--arch", default="Uformer_B")
     ap.add_argument("--img", type=int, default=256)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--loss-scale", type=float, default=0.0, help="static loss scale (default: 65536 for f16 = GradScaler's initial scale, 1 otherwise)")
     ap.add_argument("--sink", action="store_true", help="use the bucket-view gradient sink on one GPU too (exercises the overlapped path without a collective)")
     a = ap.parse_args()
     rank, local_rank, world = ud.init_process_group("nccl")
@@ -38,7 +39,8 @@ def main():
     torch.manual_seed(1234 + rank)                                                 # DropPath masks differ per rank (train/train_denoise.py:60-63 seeds 1234)
     cfg = spec.arch_config(a.arch, img_size=a.img)
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
-                   dd_in=cfg.dd_in, compute_dtype=torch.bfloat16 if a.dtype == "bf16" else torch.float32)
+                   dd_in=cfg.dd_in, compute_dtype={"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype])
+    ls = a.loss_scale if a.loss_scale > 0 else (65536.0 if a.dtype == "f16" else 1.0)
     m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
     m = m.cuda().train()
     opt = uo.AdamW(m.parameters(), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)     # train/train_denoise.py:77, on uf_adamw_step
@@ -56,10 +58,10 @@ def main():
         else:
             opt.zero_grad(set_to_none=True)
         loss = criterion(m(x), target)
-        loss.backward()
+        (loss * ls if ls != 1.0 else loss).backward()          # f16 operands: scaled loss; 1 / scale is folded into the AdamW update
         if sink is not None:
             sink.finish()
-        opt.step(grad_scale=sink.grad_scale if sink is not None else 1.0)
+        opt.step(grad_scale=(sink.grad_scale if sink is not None else 1.0) / ls)
         return loss
 
     for _ in range(a.warmup):
@@ -74,7 +76,7 @@ def main():
     dt = ud.max_over_ranks(time.perf_counter() - t0, "cuda") / a.steps
     if rank == 0:
         print(json.dumps({"metric": "training images/sec (fused fwd + recompute bwd + Charbonnier + AdamW kernels)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3,
-                          "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss": float(loss),
+                          "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss_scale": ls, "loss": float(loss),
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "ranks": world,
                           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}))
     if world > 1:

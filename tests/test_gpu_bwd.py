@@ -2,7 +2,7 @@
 oracle/uformer_oracle_bwd.py -- which tests/test_oracle_golden.py pins to the reference's own autograd.
 
 Tolerances: f32 2e-4 relative to the largest reference magnitude; bf16 operands 2.5e-2 (inputs/outputs rounded to 8 bits,
-sums in f32)."""
+sums in f32); f16 operands (11 bits: 8x finer than bf16) a quarter of the bf16 tolerance everywhere (``pick``)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -12,7 +12,15 @@ from oracle import uformer_oracle_bwd as OB
 
 pytestmark = pytest.mark.gpu
 
-TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2}
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2.5e-2, torch.float16: 2.5e-2 / 4}
+MODES = [torch.float32, torch.bfloat16, torch.float16]
+TAG = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
+F16_LOSS_SCALE = 65536.0       # torch.cuda.amp.GradScaler's initial scale (the reference trains under it, train/train_denoise.py:42,180-184)
+
+
+def pick(dtype, f32, bf16):
+    """tolerance by operand type: f16 = a quarter of bf16's (8x finer rounding, 2x headroom), never under f32's"""
+    return f32 if dtype == torch.float32 else (bf16 if dtype == torch.bfloat16 else max(f32, bf16 / 4))
 
 
 def rel(a, b):
@@ -23,7 +31,7 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_gelu_bwd(dtype):
     from uformer_amd import ops
     a = (torch.randn(3, 50, 64, generator=g(1)) * 2).to(dtype)
@@ -46,7 +54,7 @@ def test_layernorm_bwd(C, rows):
     assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32)])
 def test_dwconv3x3_backward(dtype, B, H, W, C):
     """Input gradient = the forward stencil with flipped taps (gelu off, no bias); tap / bias gradients = uf_dwconv3x3_wgrad."""
@@ -63,13 +71,13 @@ def test_dwconv3x3_backward(dtype, B, H, W, C):
     dh = ops.dwconv3x3(dc.cuda(), w9.flip(0).contiguous().cuda(), None, gelu=False)
     assert rel(dh, rdh) < TOL[dtype]
     dw9, db = ops.dwconv3x3_wgrad(h.cuda(), dc.cuda())
-    assert rel(dw9, rdw.reshape(C, 9).t()) < (2e-4 if dtype == torch.float32 else 2e-3)   # bf16: inputs exact in f32 sums
-    assert rel(db, rdb) < (2e-4 if dtype == torch.float32 else 2e-3)
+    assert rel(dw9, rdw.reshape(C, 9).t()) < pick(dtype, 2e-4, 2e-3)   # bf16: inputs exact in f32 sums
+    assert rel(db, rdb) < pick(dtype, 2e-4, 2e-3)
     dw9b, dbb = ops.dwconv3x3_wgrad(h.cuda(), dc.cuda())
     assert torch.equal(dw9, dw9b) and torch.equal(db, dbb)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512)])
 def test_linear_wgrad_and_input_grad(dtype, M, N, K):
     """dW = dY^T X, db = column sums (token-split MFMA kernel, two-stage sums) and dX = dY W through the forward GEMM."""
@@ -79,7 +87,7 @@ def test_linear_wgrad_and_input_grad(dtype, M, N, K):
     w = (torch.randn(N, K, generator=g(12)) / K ** 0.5).to(dtype)
     rdx, rdw, rdb = OB.linear_bwd(x.float(), w.float(), dy.float())
     dW, db = ops.linear_wgrad(dy.cuda(), x.cuda())
-    tol = 2e-4 if dtype == torch.float32 else 2e-3
+    tol = pick(dtype, 2e-4, 2e-3)
     assert rel(dW, rdw) < tol and rel(db, rdb) < tol
     dW2, db2 = ops.linear_wgrad(dy.cuda(), x.cuda())
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
@@ -101,7 +109,7 @@ def _attention_bwd_reference(q, k, v, bias, mask, do, heads):
     return dS @ k, dS.transpose(-2, -1) @ q, dv, dS.sum(0)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("B,H,heads,shift", [(2, 16, 2, 4), (1, 32, 1, 0), (3, 16, 4, 4), (5, 8, 2, 0)])
 def test_window_attention_bwd(dtype, B, H, heads, shift):
     from uformer_amd import ops
@@ -128,7 +136,7 @@ def test_window_attention_bwd(dtype, B, H, heads, shift):
         assert rel(dq2, flat(rdq)) < tol and rel(db2, rdb) < tol
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_lewin_block_backward_vs_reference_autograd(golden, dtype):
     """A whole LeWin block (shifted windows, 2 heads, modulator): forward + backward assembled from the C-ABI kernels
     (uformer_amd/train.py) against the gradients the REFERENCE's autograd produced (tests/golden/grad_lewin_block.npz)."""
@@ -138,7 +146,7 @@ def test_lewin_block_backward_vs_reference_autograd(golden, dtype):
     t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
     p = {k[2:]: t(v).cuda() for k, v in gd.items() if k.startswith("p.")}
     y, dx, grads = train.lewin_block_forward_backward(t(gd["x"]).cuda(), p, "", int(gd["heads"]), 4, t(gd["gy"]).cuda(), dtype)
-    tol = 1e-3 if dtype == torch.float32 else 6e-2
+    tol = pick(dtype, 1e-3, 6e-2)
     assert rel(y, t(gd["y"])) < tol
     assert rel(dx, t(gd["dx"])) < tol, rel(dx, t(gd["dx"]))
     ref = {k[2:]: t(v) for k, v in gd.items() if k.startswith("g.")}
@@ -147,7 +155,7 @@ def test_lewin_block_backward_vs_reference_autograd(golden, dtype):
     assert worst[0] < tol, worst
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_model_backward_vs_reference_autograd(golden, dtype):
     """Whole tiny32 model (9 stages, samplers, stem, head, global residual) under the reference's Charbonnier loss: forward +
     backward assembled from the C-ABI kernels (uformer_amd/train.py) against the gradients the REFERENCE's autograd produced
@@ -167,8 +175,8 @@ def test_model_backward_vs_reference_autograd(golden, dtype):
     assert abs(O.charbonnier_loss(y_ref, target).item() - float(gd["loss"])) < 1e-6
     dy = OB.charbonnier_loss_bwd(y_ref, target)
     y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype)
-    assert rel(y, y_ref) < (1e-5 if dtype == torch.float32 else 1e-2)
-    tol = 2e-3 if dtype == torch.float32 else 1e-1
+    assert rel(y, y_ref) < pick(dtype, 1e-5, 1e-2)
+    tol = pick(dtype, 2e-3, 1e-1)
     assert rel(dimg, t(gd["dx"])) < tol, rel(dimg, t(gd["dx"]))
     names = [str(n) for n in gd["param_names"]]
     assert set(grads) == set(names)
@@ -181,7 +189,7 @@ def test_model_backward_vs_reference_autograd(golden, dtype):
         assert rel(grads[kname[2:]], t(gd[kname])) < tol, (kname, rel(grads[kname[2:]], t(gd[kname])))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
     """The nn.Module boundary in train() mode: ``loss.backward()`` through uformer_amd.model.Uformer (UformerFunction over
     the C-ABI kernels) with the stochastic-depth masks the reference drew, against the reference's own train-mode forward
@@ -202,14 +210,20 @@ def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
     y = m(x)
     d = y - target
     loss = torch.mean(torch.sqrt(d * d + 1e-6))                             # CharbonnierLoss, eps = 1e-3 (losses.py:41-52)
-    tolf = 1e-5 if dtype == torch.float32 else 1e-2
-    assert rel(y.detach(), t(gd["y"])) < tolf and abs(loss.item() - float(gd["loss"])) < (1e-5 if dtype == torch.float32 else 2e-3)
-    if dtype == torch.bfloat16:      # the sign-like loss gradient must not inherit the bf16 forward error: feed the reference's
+    tolf = pick(dtype, 1e-5, 1e-2)
+    assert rel(y.detach(), t(gd["y"])) < tolf and abs(loss.item() - float(gd["loss"])) < pick(dtype, 1e-5, 2e-3)
+    ls = F16_LOSS_SCALE if dtype == torch.float16 else 1.0          # f16: scaled loss, as under the reference's GradScaler
+    if dtype != torch.float32:       # the sign-like loss gradient must not inherit the 2-byte forward error: feed the reference's
         dref = t(gd["y"]).cuda() - target
-        y.backward(dref / torch.sqrt(dref * dref + 1e-6) / dref.numel())
+        y.backward(dref / torch.sqrt(dref * dref + 1e-6) / dref.numel() * ls)
     else:
         loss.backward()
-    tol = 2e-3 if dtype == torch.float32 else 1e-1
+    if ls != 1.0:
+        x.grad.div_(ls)
+        for p_ in m.parameters():
+            if p_.grad is not None:
+                p_.grad.div_(ls)
+    tol = pick(dtype, 2e-3, 1e-1)
     assert rel(x.grad, t(gd["dx"])) < tol
     params = dict(m.named_parameters())
     worst = (0.0, "")
@@ -223,14 +237,14 @@ def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
 
 
 # ---- the separate GELU pass of the training forward (UF_TRAIN_SEPARATE_GELU, off by default until the training step is re-timed)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_gelu_fwd(dtype):
     from oracle import uformer_oracle as O
     from uformer_amd import ops
     a = (torch.randn(5, 33, 64) * 2).to(dtype)
     ref = O.gelu_erf(a.float())
     got = ops.gelu(a.cuda()).float().cpu()
-    assert (got - ref).abs().max() < (1e-6 if dtype == torch.float32 else 2.5e-2)
+    assert (got - ref).abs().max() < pick(dtype, 1e-6, 2.5e-2)
 
 
 def test_recompute_backward_matches_stored_backward_and_new_reductions():
@@ -281,13 +295,15 @@ def test_recompute_backward_matches_stored_backward_and_new_reductions():
         assert torch.allclose(got2, got + 1.0, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
     """BASELINE configs[2]/[3] geometry: Uformer-B 256x256 under the reference's Charbonnier loss.  Forward + backward through
     the C-ABI kernels against the REFERENCE's autograd (tests/golden/grad_model_B_256.npz): loss, restored image, d loss /
     d input, and EVERY one of the 719 parameter gradients through two signed random projections and a seeded gather or the
     full tensor (tests/fixture_checks.py) -- a permuted or transposed gradient cannot pass.
-    Tolerances: f32 2e-3 (of ||g|| / max|g|), bf16 1e-1, the ones of the tiny32 test above."""
+    Tolerances: f32 2e-3 (of ||g|| / max|g|), bf16 1e-1, the ones of the tiny32 test above; f16 2.5e-2 (bf16's / 4: derived from the
+    mantissa widths) with the loss scaled by 65536 as under the reference's GradScaler -- d loss / d y is 5e-6 here, below f16's
+    smallest normal number."""
     import fixture_checks as FC
     from uformer_amd import spec, train
     gd = golden("grad_model_B_256")
@@ -300,17 +316,18 @@ def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
                               num_heads=cfg.num_heads, dd_in=cfg.dd_in)
     loss_ref = O.charbonnier_loss(y_ref, target).item()
     dy = OB.charbonnier_loss_bwd(y_ref, target)
-    y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype)
-    f32 = dtype == torch.float32
-    worst = FC.check_grad_B(gd, loss_ref, y, dimg, grads, rtol=2e-3 if f32 else 1e-1, loss_tol=1e-6, y_tol=1e-3 if f32 else 8e-3)
+    y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype,
+                                                    loss_scale=F16_LOSS_SCALE if dtype == torch.float16 else 1.0)
+    # f16: the restored image meets the 1e-3 north-star tolerance like f32; gradients a quarter of the bf16 tolerance
+    worst = FC.check_grad_B(gd, loss_ref, y, dimg, grads, rtol=pick(dtype, 2e-3, 1e-1), loss_tol=1e-6, y_tol=8e-3 if dtype == torch.bfloat16 else 1e-3)
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/parity_grad_B_{'f32' if f32 else 'bf16'}.json", "w") as f:
+    with open(f"gpurun_out/parity_grad_B_{TAG[dtype]}.json", "w") as f:
         json.dump(worst, f)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 64), (4096, 128, 32), (130, 2048, 512)])
 def test_fused_training_gemm_epilogues_equal_the_two_pass_forms(dtype, M, N, K):
     """uf_linear_pre_gelu_fwd == uf_linear_fwd then uf_gelu_fwd; uf_linear_mul_dgelu == uf_linear_fwd then uf_gelu_bwd: the fused
@@ -325,10 +342,10 @@ def test_fused_training_gemm_epilogues_equal_the_two_pass_forms(dtype, M, N, K):
     c = (torch.randn(M, N, generator=g(63)) * 2).to(dtype).cuda()
     zero = torch.zeros(N, device="cuda")
     two_pass = ops.gelu_bwd(c, ops.linear(a, w, zero))
-    assert rel(ops.linear_mul_dgelu(a, w, zero, c), two_pass.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel(ops.linear_mul_dgelu(a, w, zero, c), two_pass.float().cpu()) < pick(dtype, 1e-6, 8e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32)])
 def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):
     from uformer_amd import ops
@@ -342,10 +359,10 @@ def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):
     flip = w9.flip(0).contiguous()
     # GELU' is inlined into a different instruction stream (fma contraction may differ by an ulp of the f32 product)
     two_pass = ops.gelu_bwd(a, ops.dwconv3x3(h, flip, None, gelu=False))
-    assert rel(ops.dwconv3x3_mul_dgelu(h, flip, a), two_pass.float().cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel(ops.dwconv3x3_mul_dgelu(h, flip, a), two_pass.float().cpu()) < pick(dtype, 1e-6, 8e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("shift", [0, 4])
 def test_backward_streaming_helpers(dtype, shift):
     """uf_residual_combine / uf_grad_fork / uf_qkv_grad_merge against the ATen sequences they replace (window_reverse + cast +
@@ -358,7 +375,7 @@ def test_backward_streaming_helpers(dtype, shift):
     s = torch.tensor([0.0, 1.25, 1.25]).cuda()
     st = s.repeat_interleave(H * W).reshape(M, 1)
     ref = x + ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float() * st
-    same = (lambda a, b: torch.equal(a, b)) if dtype == torch.bfloat16 else (lambda a, b: rel(a, b.cpu()) < 1e-6)   # f32 b: the kernel's a + s*b is one fma
+    same = (lambda a, b: torch.equal(a, b)) if dtype != torch.float32 else (lambda a, b: rel(a, b.cpu()) < 1e-6)   # f32 b: the kernel's a + s*b is one fma
     assert same(ops.residual_combine(x, yw, s, B, H, W, windowed=True, shift=shift), ref)
     assert torch.equal(ops.residual_combine(None, yw, None, B, H, W, windowed=True, shift=shift),
                        ops.window_reverse(yw.reshape(-1, 8, 8, C), 8, H, W, shift).reshape(M, C).float())
@@ -404,7 +421,7 @@ def test_conv3x3_bwd_direct_vs_torch_autograd(B, H, W, Cin, Cout, nchw):
     assert rel(dx, ref_dx) < 2e-5 and rel(dW, w.grad) < 2e-5 and rel(db, b.grad) < 2e-5
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("shift", [0, 4])
 def test_window_attention_bwd_merged_output(dtype, shift):
     """uf_window_attention_bwd_qkv == uf_window_attention_bwd followed by the head merge (dq times head_dim^-0.5, scaled before the
@@ -423,10 +440,10 @@ def test_window_attention_bwd_merged_output(dtype, shift):
     merge = lambda t: t.reshape(nW, heads, 64, hd).permute(0, 2, 1, 3).reshape(M, C)      # noqa: E731
     assert torch.equal(dbias, dbias2)
     assert torch.equal(dqkv[:, C:2 * C], merge(dk)) and torch.equal(dqkv[:, 2 * C:], merge(dvt.transpose(2, 3)))
-    assert rel(dqkv[:, :C], (merge(dq).float() * hd ** -0.5).cpu()) < (1e-6 if dtype == torch.float32 else 8e-3)
+    assert rel(dqkv[:, :C], (merge(dq).float() * hd ** -0.5).cpu()) < pick(dtype, 1e-6, 8e-3)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_block_level_backward_entry_points(dtype):
     """uf_lewin_block_bwd (recomputation + backward in one C call) == uf_leff_bwd after uf_lewin_attn_bwd on the same operands == the
     op-by-op tape of uformer_amd/train.py (same kernels, same order: identical bits), with DropPath scales and a modulator."""
@@ -457,7 +474,7 @@ def test_block_level_backward_entry_points(dtype):
         assert torch.equal(g_a[k], gv[k]), k
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 def test_native_block_pack_equals_the_aten_packing(dtype):
     """uf_pack_block_train (5 launches) against uformer_amd.packing / train.BlockPack (ATen casts, transposes, gathers): the fused
     forward and the block-level backward must give identical bits on either pack."""
@@ -482,7 +499,7 @@ def test_native_block_pack_equals_the_aten_packing(dtype):
         assert torch.equal(g1[k], g2[k]), k
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("C,shift", [(32, 0), (64, 4), (256, 4), (512, 0)])
 def test_layernorm_bwd_fused_reads_window_order_and_adds_residual(dtype, C, shift):
     """uf_layernorm_bwd_fused == cast + window_reverse + uf_layernorm_bwd + add: dx to rounding (fma); dgamma / dbeta sum the rows in window

@@ -22,7 +22,9 @@ pytestmark = pytest.mark.gpu
 
 F32_TOL = 2e-4
 BF16_REL = 2.5e-2
-MODES = [torch.float32, torch.bfloat16]
+F16_REL = BF16_REL / 8      # three more mantissa bits than bf16
+MODES = [torch.float32, torch.bfloat16, torch.float16]
+TAG = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 REPORT = {}
 
 
@@ -43,8 +45,8 @@ def check(name, got, ref, dtype):
     ref = ref.float()
     err = (got - ref).abs().max().item()
     scale = ref.abs().max().item()
-    tol = F32_TOL * max(1.0, scale) if dtype == torch.float32 else BF16_REL * max(1.0, scale)
-    REPORT[f"{name}[{'f32' if dtype == torch.float32 else 'bf16'}]"] = {"max_abs_err": err, "ref_max": scale, "tol": tol}
+    tol = {torch.float32: F32_TOL, torch.bfloat16: BF16_REL, torch.float16: F16_REL}[dtype] * max(1.0, scale)
+    REPORT[f"{name}[{TAG[dtype]}]"] = {"max_abs_err": err, "ref_max": scale, "tol": tol}
     assert torch.isfinite(got).all(), name
     assert err <= tol, f"{name}: max abs err {err:.3e} > {tol:.3e} (ref max {scale:.3f})"
 
@@ -163,7 +165,7 @@ def test_ln_fused_projections(ops, dtype, C, heads):
         z = O.window_partition(torch.roll(z, shifts=(-shift, -shift), dims=(1, 2)), 8).reshape(-1, 64, C)
         if m_ is not None:
             z = z + m_
-        zz = z.to(dtype).float() if dtype == torch.bfloat16 else z
+        zz = z.to(dtype).float() if dtype != torch.float32 else z
         y = zz.reshape(-1, C) @ wqkv.float().t() + bqkv
         nw = M // 64
         qr = (y[:, :C] * hd ** -0.5).reshape(nw, 64, heads, hd).permute(0, 2, 1, 3)
@@ -175,7 +177,7 @@ def test_ln_fused_projections(ops, dtype, C, heads):
         check(f"ln_qkv_k_C{C}_s{shift}", k, kr, dtype)
         check(f"ln_qkv_vt_C{C}_s{shift}", vt, vtr, dtype)
     z = O.layer_norm(x, gm, bt)
-    zz = z.to(dtype).float() if dtype == torch.bfloat16 else z
+    zz = z.to(dtype).float() if dtype != torch.float32 else z
     ref = O.gelu_erf(zz @ w1.float().t() + b1)
     got = ops.ln_linear_gelu(x.cuda(), gm.cuda(), bt.cuda(), w1.cuda(), b1.cuda())
     check(f"ln_linear_gelu_C{C}", got, ref, dtype)
@@ -258,7 +260,7 @@ def test_dwconv_linear2_fused(ops, dtype, C, H, W):
     b2 = 0.1 * torch.randn(C, generator=gen)
     x = torch.randn(B * H * W, C, generator=gen)
     h2 = O.gelu_erf(torch.nn.functional.conv2d(h1.float().permute(0, 3, 1, 2), wd, bd, padding=1, groups=hid)).permute(0, 2, 3, 1)
-    if dtype == torch.bfloat16:
+    if dtype != torch.float32:
         h2 = h2.to(dtype).float()
     ref = x + h2.reshape(-1, hid) @ w2.float().t() + b2
     got = ops.dwconv_linear2(h1.cuda(), packing.pack_dwconv(wd).cuda(), bd.cuda(), w2.cuda(), b2.cuda(), x.cuda())

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libuformer_hip.so")
 # A/B builds and out-of-tree installs: UFORMER_HIP_LIB=/path/to/libuformer_hip.so overrides the in-tree library
 LIB_PATH = os.environ.get("UFORMER_HIP_LIB", LIB_PATH)
 
-UF_F32, UF_BF16 = 0, 1
+UF_F32, UF_BF16, UF_F16 = 0, 1, 2
 
 c_int, c_void_p, c_size_t, c_float_p = C.c_int, C.c_void_p, C.c_size_t, C.c_void_p
 

@@ -16,10 +16,9 @@
 namespace uf {
 namespace {
 
-template <typename T> struct PFrag;  // build the P operand from exp'ed scores
-template <> struct PFrag<bf16> {
-    static __device__ __forceinline__ void make(Frag<bf16>& f, f32x4 a, f32x4 b) {
-        f.v = u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+template <typename T> struct PFrag {  // build the P operand from exp'ed scores (primary: the 2-byte operand types)
+    static __device__ __forceinline__ void make(Frag<T>& f, f32x4 a, f32x4 b) {
+        f.v = u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
     }
 };
 template <> struct PFrag<float> {
@@ -27,7 +26,8 @@ template <> struct PFrag<float> {
 };
 
 // V^T operand: 4 keys at p0 and 4 keys at p1
-__device__ __forceinline__ void load_vt(Frag<bf16>& f, const bf16* p0, const bf16* p1) {
+template <typename T> __device__ __forceinline__ void load_vt(Frag<T>& f, const T* p0, const T* p1) {
+    static_assert(sizeof(T) == 2, "2-byte operand type");
     const u32x2 a = *reinterpret_cast<const u32x2*>(p0);
     const u32x2 b = *reinterpret_cast<const u32x2*>(p1);
     f.v = u32x4{a[0], a[1], b[0], b[1]};
@@ -195,7 +195,7 @@ extern "C" int uf_window_attention_fwd(const void* q, const void* k, const void*
     hipStream_t st = (hipStream_t)stream;
     const double el = (double)n_pairs * 64 * head_dim;
     char tname[64] = "";
-    if (timing_enabled()) snprintf(tname, sizeof(tname), "window_attn_%s %dx%dx%d", dtype == UF_BF16 ? "bf16" : "f32", n_windows, heads, head_dim);
+    if (timing_enabled()) snprintf(tname, sizeof(tname), "window_attn_%s %dx%dx%d", dtype_name(dtype), n_windows, heads, head_dim);
     ScopedTimer tm(tname, 4.0 * 64 * el,
                    4.0 * el * dtype_size(dtype), st);
 #define UF_ATTN_LAUNCH(TT, HDV)                                                                                  \
@@ -203,6 +203,8 @@ extern "C" int uf_window_attention_fwd(const void* q, const void* k, const void*
                        (const TT*)vt, bias_dense, mask, n_mask, (TT*)out, n_pairs, heads, H, W, shift)
     if (dtype == UF_BF16) {
         if (head_dim == 32) UF_ATTN_LAUNCH(bf16, 32); else UF_ATTN_LAUNCH(bf16, 16);
+    } else if (dtype == UF_F16) {
+        if (head_dim == 32) UF_ATTN_LAUNCH(f16, 32); else UF_ATTN_LAUNCH(f16, 16);
     } else if (dtype == UF_F32) {
         if (head_dim == 32) UF_ATTN_LAUNCH(float, 32); else UF_ATTN_LAUNCH(float, 16);
     } else {

@@ -80,10 +80,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define UF_FC1_RING 5
 #endif
 
-template <typename T> struct FragFromAcc;
-template <> struct FragFromAcc<bf16> {
-    static __device__ __forceinline__ void make(Frag<bf16>& f, f32x4 a, f32x4 b) {
-        f.v = u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+template <typename T> struct FragFromAcc {   // primary: the 2-byte operand types
+    static __device__ __forceinline__ void make(Frag<T>& f, f32x4 a, f32x4 b) {
+        f.v = u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
     }
 };
 template <> struct FragFromAcc<float> {
@@ -109,7 +108,7 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
     // RING k-steps of weight fragments in flight: one k-step is only 16 MFMAs (256 cycles) per wave, an L2 round trip under
     // load is 1-2 K cycles -- with 3 slots the walk stalled on every k-step (stamps: 3-4x the MFMA time); 16 registers a slot
     constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / 64;
-    static_assert(SZ == 2, "direct-store epilogue packs bf16 pairs");
+    static_assert(SZ == 2, "direct-store epilogue packs pairs of a 2-byte type");
     const int fr = lane & 15, fg = lane >> 4;
     const T* wrow[4];
     Frag<T> wf[RING][4];
@@ -168,8 +167,8 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
             for (int ip = 0; ip < 4; ip += 2) {
                 f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
                 gelu4<T>(va); gelu4<T>(vb);
-                const unsigned a0 = pack2bf(va[0], va[1]), a1 = pack2bf(va[2], va[3]);
-                const unsigned c0 = pack2bf(vb[0], vb[1]), c1 = pack2bf(vb[2], vb[3]);
+                const unsigned a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
+                const unsigned c0 = pack2<T>(vb[0], vb[1]), c1 = pack2<T>(vb[2], vb[3]);
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
                 const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
@@ -637,7 +636,7 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "attn_block")) return rc;
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", p.h1 ? "_fc1" : "", sizeof(T) == 2 ? "bf16" : "f32", C, NT, p.n_windows * 64, C);
+        snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", p.h1 ? "_fc1" : "", TypeName<T>::s, C, NT, p.n_windows * 64, C);
     const double M = (double)p.n_windows * 64;
     const double fc1_flops = p.h1 ? 2.0 * M * C * 4.0 * C : 0.0, fc1_bytes = p.h1 ? M * 4.0 * C * sizeof(T) + 4.0 * C * C * sizeof(T) : 0.0;
     {
@@ -661,7 +660,7 @@ bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_
     // one -- and no caller-supplied mask; everything else takes the 3-kernel path
     if (!bp->rpb_tab || user_mask) return false;
     if (heads <= 0 || C != heads * 32) return false;
-    if (dtype == UF_BF16) return C == 32 || C == 64 || C == 128 || C == 256 || C == 512;
+    if (dtype_half(dtype)) return C == 32 || C == 64 || C == 128 || C == 256 || C == 512;
     return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
 }
 
@@ -672,22 +671,26 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;
     p.gamma2 = bp->norm2_w; p.beta2 = bp->norm2_b; p.W1 = bp->w1_fm; p.b1 = bp->b1;
-    p.h1 = dtype == UF_BF16 ? h1_out : nullptr;   // phase 3 exists for 2-byte operands only
+    p.h1 = dtype_half(dtype) ? h1_out : nullptr;   // phase 3 exists for 2-byte operands only
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = debug_get_tbuf();
 
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
-    if (dtype == UF_BF16) {
-        switch (C) {
-            case 32: UF_AB(bf16, 32, 256);
-            case 64: UF_AB(bf16, 64, 256);
-            case 128: UF_AB(bf16, 128, 256);
-            case 256:
-                if (p.n_windows <= 256) UF_AB(bf16, 256, 512);   // one workgroup per CU at most: 8 waves (one head each) instead of 4
-                UF_AB(bf16, 256, 256);
-            case 512: UF_AB(bf16, 512, 512);
+#define UF_AB_HALF(TT)                                                                                                              \
+        switch (C) {                                                                                                                    \
+            case 32: UF_AB(TT, 32, 256);                                                                                                \
+            case 64: UF_AB(TT, 64, 256);                                                                                                \
+            case 128: UF_AB(TT, 128, 256);                                                                                              \
+            case 256:                                                                                                                   \
+                if (p.n_windows <= 256) UF_AB(TT, 256, 512);   /* one workgroup per CU at most: 8 waves (one head each) instead of 4 */ \
+                UF_AB(TT, 256, 256);                                                                                                    \
+            case 512: UF_AB(TT, 512, 512);                                                                                              \
         }
+    if (dtype == UF_BF16) {
+        UF_AB_HALF(bf16)
+    } else if (dtype == UF_F16) {
+        UF_AB_HALF(f16)
     } else {
         switch (C) {
             case 32: UF_AB(float, 32, 256);
@@ -696,6 +699,7 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
             case 256: UF_AB(float, 256, 256);
         }
     }
+#undef UF_AB_HALF
 #undef UF_AB
     set_error("attn_block: unsupported C=%d for dtype %d", C, (int)dtype);
     return UF_ERR_UNSUPPORTED;

@@ -16,17 +16,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 // (uf_common.h gelu_grad_t: the erf form for f32 operands, the derivative of the bf16 forward's own GELU for bf16 operands)
 
-template <typename T> struct Vec;
-template <> struct Vec<bf16> {
+template <typename T> struct Vec {   // primary: the 2-byte operand types (bf16, f16)
+    static_assert(sizeof(T) == 2, "2-byte operand type");
     static constexpr int N = 8;
-    static __device__ __forceinline__ void load(const bf16* p, float* f) {
-        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
-    }
-    static __device__ __forceinline__ void store(bf16* p, const float* f) {
-        *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
-    }
+    static __device__ __forceinline__ void load(const T* p, float* f) { unpack8<T>(*reinterpret_cast<const u32x4*>(p), f); }
+    static __device__ __forceinline__ void store(T* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack8<T>(f); }
 };
 template <> struct Vec<float> {
     static constexpr int N = 4;
@@ -73,12 +67,14 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T* __restrict__ a, 
 // dy: f32 or the operand type (TD); rows of dy are indexed by m, rows of x / add / dx by tok(m) = m, or -- win_h > 0 -- the token of
 // window-order row m (dy still in the order the attention half produced it: window_reverse + roll back folded in); add (optional):
 // a second gradient of the same tensor summed into dx (the residual path).
-template <typename TD> __device__ __forceinline__ f32x4 load_dy4(const TD* p);
-template <> __device__ __forceinline__ f32x4 load_dy4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> __device__ __forceinline__ f32x4 load_dy4<bf16>(const bf16* p) {
+template <typename TD> __device__ __forceinline__ f32x4 load_dy4(const TD* p) {   // primary: the 2-byte operand types
     const u32x2 r = *reinterpret_cast<const u32x2*>(p);
-    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16), __uint_as_float(r[1] & 0xffff0000u)};
+    float a, b, c, d;
+    unpack2<TD>(r[0], a, b);
+    unpack2<TD>(r[1], c, d);
+    return f32x4{a, b, c, d};
 }
+template <> __device__ __forceinline__ f32x4 load_dy4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 template <int C, typename TD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ gamma,
@@ -419,7 +415,8 @@ __device__ __forceinline__ unsigned wg2_off(int row, int chunk) {     // byte of
     return (unsigned)(row * 256 + ((chunk ^ (rho << 2)) << 3));
 }
 
-__global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const bf16* __restrict__ dY, int ldy, const bf16* __restrict__ X, int ldx,
+template <typename T>
+__global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ X, int ldx,
                                                                float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K) {
     __shared__ __attribute__((aligned(16))) char Ys[2][32 * 256];
     __shared__ __attribute__((aligned(16))) char Xs[2][32 * 256];
@@ -438,8 +435,8 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const bf16* __res
     const int prow = tid >> 4, pseg = tid & 15;
     const int cn = n0 + pseg * 8, ck = k0 + pseg * 8;
     const bool okn = cn < N, okk = ck < K;                   // N, K are multiples of 8: a piece is entirely in or out
-    const bf16* ysrc = dY + (okn ? cn : 0);
-    const bf16* xsrc = X + (okk ? ck : 0);
+    const T* ysrc = dY + (okn ? cn : 0);
+    const T* xsrc = X + (okk ? ck : 0);
     u32x4 ry[2], rx[2];
     auto fetch = [&](int s) {
 #pragma unroll
@@ -463,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const bf16* __res
             *reinterpret_cast<u32x4*>(Xs[buf] + wg2_off(row, pseg * 2)) = zx;
             if (do_bias) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { bsum[2 * e] += __uint_as_float(zy[e] << 16); bsum[2 * e + 1] += __uint_as_float(zy[e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(zy[e], lo, hi); bsum[2 * e] += lo; bsum[2 * e + 1] += hi; }
             }
         }
     };
@@ -510,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const bf16* __res
               "=&v"(x0[0]), "=&v"(x1[0]), "=&v"(x0[1]), "=&v"(x1[1]), "=&v"(x0[2]), "=&v"(x1[2]), "=&v"(x0[3]), "=&v"(x1[3])
             : "v"(ya0), "v"(ya1), "v"(ya2), "v"(ya3), "v"(xa0), "v"(xa1), "v"(xa2), "v"(xa3)
             : "memory");
-        Frag<bf16> a[4], b[4];
+        Frag<T> a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             a[i].v = u32x4{y0[i][0], y0[i][1], y1[i][0], y1[i][1]};
@@ -712,7 +709,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
                 }
                 // dv^T tile: lane holds d = 16c + 4fg + 0..3 of key token i0 + fr: four consecutive channels of one row
                 T* dst = row0 + (size_t)(i0 + fr) * C3 + 2 * heads * HD + 16 * c + 4 * fg;
-                if constexpr (SZ == 2) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2bf(ov[c][0], ov[c][1]), pack2bf(ov[c][2], ov[c][3])};
+                if constexpr (SZ == 2) *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(ov[c][0], ov[c][1]), pack2<T>(ov[c][2], ov[c][3])};
                 else *reinterpret_cast<f32x4*>(dst) = ov[c];
             }
         } else {
@@ -741,29 +738,27 @@ using namespace uf;
 
 extern "C" int uf_gelu_bwd(const void* a, const void* dy, void* dx, long long n, uf_dtype dtype, void* stream) {
     UF_REQUIRE(a && dy && dx, UF_ERR_NULL, "uf_gelu_bwd: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_gelu_bwd: dtype %d", (int)dtype);
-    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_gelu_bwd: dtype %d", (int)dtype);
+    const int N = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(n > 0 && n % N == 0, UF_ERR_SHAPE, "uf_gelu_bwd: n=%lld must be a positive multiple of %d", n, N);
     UF_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)dy % 16) == 0 && ((uintptr_t)dx % 16) == 0, UF_ERR_ALIGN, "uf_gelu_bwd: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long nvec = n / N;
     const dim3 grid((unsigned)((nvec + 255) / 256));
-    if (dtype == UF_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (const bf16*)dy, (bf16*)dx, nvec);
-    else hipLaunchKernelGGL(gelu_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (const float*)dy, (float*)dx, nvec);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(gelu_bwd_kernel<TT>, grid, dim3(256), 0, st, (const TT*)a, (const TT*)dy, (TT*)dx, nvec));
     return check_launch("gelu_bwd");
 }
 
 extern "C" int uf_gelu_fwd(const void* a, void* y, long long n, uf_dtype dtype, void* stream) {
     UF_REQUIRE(a && y, UF_ERR_NULL, "uf_gelu_fwd: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_gelu_fwd: dtype %d", (int)dtype);
-    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_gelu_fwd: dtype %d", (int)dtype);
+    const int N = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(n > 0 && n % N == 0, UF_ERR_SHAPE, "uf_gelu_fwd: n=%lld must be a positive multiple of %d", n, N);
     UF_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)y % 16) == 0, UF_ERR_ALIGN, "uf_gelu_fwd: operands must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const long long nvec = n / N;
     const dim3 grid((unsigned)((nvec + 255) / 256));
-    if (dtype == UF_BF16) hipLaunchKernelGGL(gelu_fwd_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)a, (bf16*)y, nvec);
-    else hipLaunchKernelGGL(gelu_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)a, (float*)y, nvec);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(gelu_fwd_kernel<TT>, grid, dim3(256), 0, st, (const TT*)a, (TT*)y, nvec));
     return check_launch("gelu_fwd");
 }
 
@@ -791,6 +786,7 @@ static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const flo
         const int nblk = (rows + RPB - 1) / RPB, grid = nblk < LN_BWD_MAX_BLOCKS ? nblk : LN_BWD_MAX_BLOCKS;                  \
         slots = grid * RPB;                                                                                                   \
         if (f32dy) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, float>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const float*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
+        else if (dtype == UF_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, f16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const f16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
         else hipLaunchKernelGGL((layernorm_bwd_kernel<CV, bf16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const bf16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
         break;                                                                                                                \
     }
@@ -824,14 +820,14 @@ extern "C" int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, co
 extern "C" int uf_layernorm_bwd_fused(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32, const float* add, float* dx, int ld_dx,
                                       float* dgamma, float* dbeta, int B, int H, int W, int C, int windowed, int shift, uf_dtype dtype, void* ws, size_t ws_bytes,
                                       void* stream) {
-    UF_REQUIRE(B > 0 && H > 0 && W > 0 && (dtype == UF_BF16 || dtype == UF_F32), UF_ERR_SHAPE, "uf_layernorm_bwd_fused: B=%d H=%d W=%d dtype=%d", B, H, W, (int)dtype);
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && dtype_ok(dtype), UF_ERR_SHAPE, "uf_layernorm_bwd_fused: B=%d H=%d W=%d dtype=%d", B, H, W, (int)dtype);
     UF_REQUIRE(dy_is_f32 || dtype == UF_F32 || ld_dy % 8 == 0, UF_ERR_ALIGN, "uf_layernorm_bwd_fused: ld_dy=%d", ld_dy);
     return layernorm_bwd_any("uf_layernorm_bwd_fused", x, ld_x, gamma, dy, ld_dy, dy_is_f32, dtype, add, dx, ld_dx, dgamma, dbeta, B * H * W, C, windowed ? H : 0, windowed ? W : 0,
                              shift, ws, ws_bytes, stream);
 }
 
 extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {
-    const int N = dtype == UF_BF16 ? 8 : 4;
+    const int N = dtype_half(dtype) ? 8 : 4;
     if (C <= 0 || C % N) return 0;
     const int cv = C / N;
     int blocks = dw_wgrad_blocks();
@@ -842,8 +838,8 @@ extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {
 extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C, uf_dtype dtype,
                                   void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(h && dc && dw9 && dbias && ws, UF_ERR_NULL, "uf_dwconv3x3_wgrad: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_dwconv3x3_wgrad: dtype %d", (int)dtype);
-    const int N = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_dwconv3x3_wgrad: dtype %d", (int)dtype);
+    const int N = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % N == 0 && H % DWB_R == 0, UF_ERR_SHAPE,
                "uf_dwconv3x3_wgrad: B=%d H=%d W=%d C=%d (C multiple of %d, H multiple of %d)", B, H, W, C, N, DWB_R);
     UF_REQUIRE((long long)B * H * W * C < 0x7fffffffLL, UF_ERR_SHAPE, "uf_dwconv3x3_wgrad: tensor too large");
@@ -852,8 +848,7 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     hipStream_t st = (hipStream_t)stream;
     const int cv = C / N;
     const int blocks = (int)(need / (256 * 10 * N * sizeof(float)));
-    if (dtype == UF_BF16) hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<bf16>, dim3(blocks), dim3(256), 0, st, (const bf16*)h, (const bf16*)dc, (float*)ws, B, H, W, C);
-    else hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)h, (const float*)dc, (float*)ws, B, H, W, C);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(dwconv3x3_wgrad_kernel<TT>, dim3(blocks), dim3(256), 0, st, (const TT*)h, (const TT*)dc, (float*)ws, B, H, W, C));
     int rc = check_launch("dwconv3x3_wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(dwconv3x3_wgrad_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, (long long)blocks * 256, cv, N, dw9, dbias, C);
@@ -862,7 +857,7 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
 
 static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullptr; return !off; }   // UF_WGRAD_V1=1: first version (A/B, tests)
 static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
-    const int T = (dtype == UF_BF16 && wgrad_v2()) ? 128 : 64;
+    const int T = (dtype_half(dtype) && wgrad_v2()) ? 128 : 64;
     const int tiles = ((N + T - 1) / T) * ((K + T - 1) / T), steps = (M + 31) / 32;
     // workgroups per launch to aim for: every chunk costs one N x K f32 partial written and read again by the ordered sum, so no more
     // chunks than it takes to fill the chip (128-wide tiles: 2 workgroups per CU resident; UF_WGRAD_TARGET overrides, for A/B runs)
@@ -883,27 +878,27 @@ extern "C" size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K) {
 extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
                                uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(dY && X && dW && ws, UF_ERR_NULL, "uf_linear_wgrad: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_linear_wgrad: dtype %d", (int)dtype);
-    const int EP = dtype == UF_BF16 ? 8 : 4;
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_linear_wgrad: dtype %d", (int)dtype);
+    const int EP = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(M > 0 && N >= EP && K >= EP && N % EP == 0 && K % EP == 0 && ldy >= N && ldx >= K && ldy % EP == 0 && ldx % EP == 0, UF_ERR_SHAPE,
                "uf_linear_wgrad: M=%d N=%d K=%d ld=(%d,%d) (N, K, ld multiples of %d)", M, N, K, ldy, ldx, EP);
     UF_REQUIRE(((uintptr_t)dY % 16) == 0 && ((uintptr_t)X % 16) == 0, UF_ERR_ALIGN, "uf_linear_wgrad: operands must be 16-byte aligned");
     const size_t need = uf_linear_wgrad_workspace_bytes(M, N, K);
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_linear_wgrad: workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
-    const bool v2 = dtype == UF_BF16 && wgrad_v2();
+    const bool v2 = dtype_half(dtype) && wgrad_v2();
     const int S = wgrad_chunks(M, N, K, dtype);
     float* ws_w = (float*)ws;
     float* ws_b = ws_w + (size_t)S * N * K;
     const int TT = v2 ? 128 : 64;
     const dim3 grid(((N + TT - 1) / TT) * ((K + TT - 1) / TT), S);
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype == UF_BF16 ? "bf16" : "f32", M, N, K);
+    if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype_name(dtype), M, N, K);
     {
         ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
-        if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
-        else if (dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
-        else hipLaunchKernelGGL(linear_wgrad_kernel<float>, grid, dim3(256), 0, st, (const float*)dY, ldy, (const float*)X, ldx, ws_w, ws_b, M, N, K);
+        if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
+        else if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel<f16>, grid, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K);
+        else UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(linear_wgrad_kernel<TT>, grid, dim3(256), 0, st, (const TT*)dY, ldy, (const TT*)X, ldx, ws_w, ws_b, M, N, K));
     }
     int rc = check_launch("linear_wgrad");
     if (rc) return rc;
@@ -928,14 +923,14 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
                                     const void* dO, int ldo, void* dq, void* dk, void* dvt, void* dqkv, float* dbias, int n_windows, int heads,
                                     int head_dim, int H, int W, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(q && k && vt && bias_dense && dO && ((dq && dk && dvt) || dqkv) && dbias && ws, UF_ERR_NULL, "uf_window_attention_bwd: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: dtype %d", (int)dtype);
     UF_REQUIRE(n_windows > 0 && heads > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: n_windows=%d heads=%d", n_windows, heads);
     UF_REQUIRE(head_dim == 32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: head_dim %d (32 only so far)", head_dim);
     UF_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && n_windows % ((H / 8) * (W / 8)) == 0, UF_ERR_SHAPE,
                "uf_window_attention_bwd: H=%d W=%d n_windows=%d", H, W, n_windows);
     UF_REQUIRE(shift == 0 || shift == 4, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: shift %d (0 or 4)", shift);
     UF_REQUIRE(!mask || n_mask > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: mask given with n_mask=%d", n_mask);
-    const int EP = dtype == UF_BF16 ? 8 : 4;
+    const int EP = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(ldo >= heads * head_dim && ldo % EP == 0, UF_ERR_ALIGN, "uf_window_attention_bwd: ldo=%d", ldo);
     const size_t need = uf_window_attention_bwd_workspace_bytes(n_windows, heads);
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_window_attention_bwd: workspace too small: %zu < %zu", ws_bytes, need);
@@ -945,21 +940,16 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
     const int SZ = (int)dtype_size(dtype);
     const int smem = 4 * 64 * (32 * SZ + 16) + 3 * 32 * (64 * SZ + 16) + 4 * 64 * (64 * SZ + 16);
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "window_attn_bwd_%s %dx%d", dtype == UF_BF16 ? "bf16" : "f32", n_windows, heads);
+    if (timing_enabled()) snprintf(name, sizeof(name), "window_attn_bwd_%s %dx%d", dtype_name(dtype), n_windows, heads);
     {
         const double pairs = (double)n_windows * heads;
         ScopedTimer tm(name, 2.0 * 5 * 64 * 64 * 32 * pairs, pairs * 64 * 32 * 7.0 * SZ, st);
-        if (dtype == UF_BF16) {
+        UF_DISPATCH(dtype, TT, {
             static bool done[64] = {};
-            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16>), smem, done, "window_attn_bwd")) return rc;
-            hipLaunchKernelGGL(window_attn_bwd_kernel<bf16>, dim3(heads, G), dim3(256), smem, st, (const bf16*)q, (const bf16*)k, (const bf16*)vt,
-                               bias_dense, mask, n_mask, (const bf16*)dO, ldo, (bf16*)dq, (bf16*)dk, (bf16*)dvt, (bf16*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
-        } else {
-            static bool done[64] = {};
-            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<float>), smem, done, "window_attn_bwd")) return rc;
-            hipLaunchKernelGGL(window_attn_bwd_kernel<float>, dim3(heads, G), dim3(256), smem, st, (const float*)q, (const float*)k, (const float*)vt,
-                               bias_dense, mask, n_mask, (const float*)dO, ldo, (float*)dq, (float*)dk, (float*)dvt, (float*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
-        }
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<TT>), smem, done, "window_attn_bwd")) return rc;
+            hipLaunchKernelGGL(window_attn_bwd_kernel<TT>, dim3(heads, G), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)vt,
+                               bias_dense, mask, n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
+        });
     }
     int rc = check_launch("window_attn_bwd");
     if (rc) return rc;
@@ -1091,14 +1081,13 @@ static int rows_sum_parts(int M) { return M < 128 ? M : 128; }
 extern "C" size_t uf_rows_sum_workspace_bytes(int M, int N) { return M <= 0 || N <= 0 ? 0 : (size_t)rows_sum_parts(M) * N * sizeof(float); }
 extern "C" int uf_rows_sum(const void* X, int ld, float* out, int M, int N, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(X && out && ws, UF_ERR_NULL, "uf_rows_sum: null pointer");
-    const int V = dtype == UF_BF16 ? 8 : 4;
+    const int V = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(M > 0 && N > 0 && N % V == 0 && ld >= N && ld % V == 0 && ((uintptr_t)X % 16) == 0, UF_ERR_SHAPE, "uf_rows_sum: M=%d N=%d ld=%d (N, ld multiples of %d)", M, N, ld, V);
     UF_REQUIRE(ws_bytes >= uf_rows_sum_workspace_bytes(M, N), UF_ERR_WORKSPACE, "uf_rows_sum: workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int P = rows_sum_parts(M);
     const dim3 grid((N / V + 255) / 256, P);
-    if (dtype == UF_BF16) hipLaunchKernelGGL(rows_partial_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)X, ld, (float*)ws, M, N, P);
-    else hipLaunchKernelGGL(rows_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)X, ld, (float*)ws, M, N, P);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(rows_partial_kernel<TT>, grid, dim3(256), 0, st, (const TT*)X, ld, (float*)ws, M, N, P));
     hipLaunchKernelGGL(column_sum_kernel, dim3((N + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, (const float*)ws, P, (size_t)N, out, N);
     return check_launch("rows_sum");
 }
@@ -1115,8 +1104,7 @@ extern "C" int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, i
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long long total = (long long)B * Ho * Wo * ldc;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == UF_BF16) hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (bf16*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw);
-    else hipLaunchKernelGGL(im2col_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (float*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(im2col_kernel<TT>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (TT*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw));
     return check_launch("im2col");
 }
 
@@ -1127,8 +1115,7 @@ extern "C" int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long long total = (long long)B * H * W * Cin;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == UF_BF16) hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(grid1d(total)), dim3(256), 0, st, (const bf16*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate);
-    else hipLaunchKernelGGL(col2im_kernel<float>, dim3(grid1d(total)), dim3(256), 0, st, (const float*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(col2im_kernel<TT>, dim3(grid1d(total)), dim3(256), 0, st, (const TT*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate));
     return check_launch("col2im");
 }
 
@@ -1139,11 +1126,9 @@ extern "C" int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B
 namespace uf {
 namespace {
 
-template <typename T> __device__ __forceinline__ void load8(const T* p, float* f);
-template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float* f) { Vec<bf16>::load(p, f); }
+template <typename T> __device__ __forceinline__ void load8(const T* p, float* f) { Vec<T>::load(p, f); }   // 2-byte types
 template <> __device__ __forceinline__ void load8<float>(const float* p, float* f) { Vec<float>::load(p, f); Vec<float>::load(p + 4, f + 4); }
-template <typename T> __device__ __forceinline__ void store8(T* p, const float* f);
-template <> __device__ __forceinline__ void store8<bf16>(bf16* p, const float* f) { Vec<bf16>::store(p, f); }
+template <typename T> __device__ __forceinline__ void store8(T* p, const float* f) { Vec<T>::store(p, f); }   // 2-byte types
 template <> __device__ __forceinline__ void store8<float>(float* p, const float* f) { Vec<float>::store(p, f); Vec<float>::store(p + 4, f + 4); }
 
 // out[tok] = (a ? a[tok] : 0) + s(tok) * b[row],  row = the window-order index of tok when `windowed` (b is in window order: this
@@ -1230,8 +1215,7 @@ extern "C" int uf_residual_combine(const float* a, const void* b, int b_is_f32, 
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && (!windowed || (H % 8 == 0 && W % 8 == 0)), UF_ERR_SHAPE, "uf_residual_combine: B=%d H=%d W=%d C=%d", B, H, W, C);
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid1d((long long)B * H * W * (C / 8));
-    if (b_is_f32 || dtype == UF_F32) hipLaunchKernelGGL(residual_combine_kernel<float>, dim3(grid), dim3(256), 0, st, a, (const float*)b, out, scale, B, H, W, C, windowed, shift);
-    else hipLaunchKernelGGL(residual_combine_kernel<bf16>, dim3(grid), dim3(256), 0, st, a, (const bf16*)b, out, scale, B, H, W, C, windowed, shift);
+    UF_DISPATCH(b_is_f32 ? UF_F32 : dtype, TT, hipLaunchKernelGGL(residual_combine_kernel<TT>, dim3(grid), dim3(256), 0, st, a, (const TT*)b, out, scale, B, H, W, C, windowed, shift));
     return check_launch("residual_combine");
 }
 
@@ -1241,8 +1225,7 @@ extern "C" int uf_grad_fork(const float* g1, const float* g2, float* sum_out, vo
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C % 8 == 0 && (!windowed || (H % 8 == 0 && W % 8 == 0)), UF_ERR_SHAPE, "uf_grad_fork: B=%d H=%d W=%d C=%d", B, H, W, C);
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid1d((long long)B * H * W * (C / 8));
-    if (dtype == UF_F32) hipLaunchKernelGGL(grad_fork_kernel<float>, dim3(grid), dim3(256), 0, st, g1, g2, sum_out, (float*)cast_out, scale, B, H, W, C, windowed, shift);
-    else hipLaunchKernelGGL(grad_fork_kernel<bf16>, dim3(grid), dim3(256), 0, st, g1, g2, sum_out, (bf16*)cast_out, scale, B, H, W, C, windowed, shift);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(grad_fork_kernel<TT>, dim3(grid), dim3(256), 0, st, g1, g2, sum_out, (TT*)cast_out, scale, B, H, W, C, windowed, shift));
     return check_launch("grad_fork");
 }
 
@@ -1252,8 +1235,7 @@ extern "C" int uf_qkv_grad_merge(const void* dq, const void* dk, const void* dvt
     hipStream_t st = (hipStream_t)stream;
     const int grid = grid1d((long long)n_windows * 64 * heads * 12);
     const float qs = (float)(1.0 / sqrt((double)head_dim));   // python: head_dim ** -0.5, rounded once to f32
-    if (dtype == UF_F32) hipLaunchKernelGGL(qkv_grad_merge_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dq, (const float*)dk, (const float*)dvt, (float*)dqkv, n_windows, heads, qs);
-    else hipLaunchKernelGGL(qkv_grad_merge_kernel<bf16>, dim3(grid), dim3(256), 0, st, (const bf16*)dq, (const bf16*)dk, (const bf16*)dvt, (bf16*)dqkv, n_windows, heads, qs);
+    UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(qkv_grad_merge_kernel<TT>, dim3(grid), dim3(256), 0, st, (const TT*)dq, (const TT*)dk, (const TT*)dvt, (TT*)dqkv, n_windows, heads, qs));
     return check_launch("qkv_grad_merge");
 }
 

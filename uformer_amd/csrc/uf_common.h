@@ -11,10 +11,14 @@
 namespace uf {
 
 // ------------------------------------------------------------------------------------
-// element types.  T = operand/activation type (bf16 or f32), R = residual stream = f32.
+// element types.  T = operand/activation type (bf16, f16 or f32), R = residual stream = f32.
+// f16 is the reference's own reduced-precision mode (torch.cuda.amp autocast, train/train_denoise.py:180-184): same MFMA
+// rate and fragment layout as bf16 on gfx950, three more mantissa bits.
 // ------------------------------------------------------------------------------------
 struct bf16 { uint16_t v; };
+struct f16 { uint16_t v; };
 typedef __attribute__((ext_vector_type(8))) __bf16 mfma_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 mfma_f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
@@ -28,6 +32,36 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
     const bf16x2_t v = {static_cast<__bf16>(lo), static_cast<__bf16>(hi)};
     return __builtin_bit_cast(uint32_t, v);
 }
+
+// float <-> f16: round-to-nearest-even conversions through the compiler (v_cvt_f16_f32 / v_cvt_pk_f16_f32, v_cvt_f32_f16)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float h2f(uint16_t h) { return static_cast<float>(__builtin_bit_cast(_Float16, h)); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, static_cast<_Float16>(f)); }
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+    const f16x2_t v = {static_cast<_Float16>(lo), static_cast<_Float16>(hi)};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// the 2-byte operand types behind one interface: pack2<T>(lo, hi) -> one dword, unpack2<T>(w, lo, hi), cvt1<T> / ld1<T>
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<bf16>(float lo, float hi) { return pack2bf(lo, hi); }
+template <> __device__ __forceinline__ uint32_t pack2<f16>(float lo, float hi) { return pack2h(lo, hi); }
+template <typename T> __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi);
+template <> __device__ __forceinline__ void unpack2<bf16>(uint32_t w, float& lo, float& hi) { lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xffff0000u); }
+template <> __device__ __forceinline__ void unpack2<f16>(uint32_t w, float& lo, float& hi) {
+    const f16x2_t v = __builtin_bit_cast(f16x2_t, w);
+    lo = static_cast<float>(v[0]); hi = static_cast<float>(v[1]);
+}
+template <typename T> __device__ __forceinline__ u32x4 pack8(const float* f) {
+    return u32x4{pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3]), pack2<T>(f[4], f[5]), pack2<T>(f[6], f[7])};
+}
+template <typename T> __device__ __forceinline__ void unpack8(u32x4 r, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) unpack2<T>(r[i], f[2 * i], f[2 * i + 1]);
+}
+template <typename T> struct TypeName;
+template <> struct TypeName<bf16> { static constexpr const char* s = "bf16"; };
+template <> struct TypeName<f16> { static constexpr const char* s = "f16"; };
+template <> struct TypeName<float> { static constexpr const char* s = "f32"; };
 
 // exact erf GELU (nn.GELU default; reference model.py:657-660)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -63,9 +97,33 @@ __device__ __forceinline__ f32x2_t gelu_bf2(f32x2_t x) {
     return x * f32x2_t{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
 #endif
 }
+// Which GELU the operand type T gets.  bf16: the packed sigmoid form above.  f16: the same form by default -- the whole Uformer-B output
+// moves by 5.8e-5 with it (oracle/bf16_budget.py row "sigmoid-form GELU"), a twentieth of the 1e-3 output tolerance, while an
+// erf-accurate form doubles the VALU work of every activation (two GELUs per hidden channel and token); UF_F16_GELU_ERF=1 builds the
+// f16 kernels with the Abramowitz-Stegun erf form below instead (|GELU error| < 5e-7) for A/B runs.  f32: erff.
+#ifndef UF_F16_GELU_ERF
+#define UF_F16_GELU_ERF 0
+#endif
+template <typename T> struct GeluKind { static constexpr int v = 0; };                          // 0: erff (f32 parity mode)
+template <> struct GeluKind<bf16> { static constexpr int v = 1; };                              // 1: packed sigmoid form
+template <> struct GeluKind<f16> { static constexpr int v = UF_F16_GELU_ERF ? 2 : 1; };        // 2: A-S 7.1.26 erf
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): GELU(x) = max(x, 0) - 0.5 |x| P(t) exp(-z^2), z = |x| / sqrt(2), t = 1 / (1 + p z)
+__device__ __forceinline__ float gelu_as(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f) * t;
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    return fmaf(-0.70710678118654752440f * z, q * e, fmaxf(x, 0.0f));
+}
 // in-place GELU of N (even) values in the flavour the operand type T calls for
 template <typename T, int N> __device__ __forceinline__ void gelu_n(float* v) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (GeluKind<T>::v == 2) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = gelu_as(v[i]);
+    } else if constexpr (GeluKind<T>::v == 1) {
 #pragma unroll
         for (int i = 0; i < N; i += 2) {
             const f32x2_t g = gelu_bf2(f32x2_t{v[i], v[i + 1]});
@@ -80,7 +138,7 @@ template <typename T, int N> __device__ __forceinline__ void gelu_n(float* v) {
 // bf16 forward evaluates), s + a e s^2 (2k + 6k 0.044715 a^2) with e = exp(-2u), s = 1 / (1 + e): one exp2 and one rcp instead of
 // erff + expf.  It differs from the erf form by < 8.7e-4 absolute, under half a bf16 ulp of the O(1) result it is rounded to.
 template <typename T> __device__ __forceinline__ float gelu_grad_t(float a) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (GeluKind<T>::v == 1) {
         constexpr float A = -2.3022081985f, B = -0.10294324f;                 // as gelu_bf2
         const float u = fminf(a * (a * a * B + A), 80.0f);                   // e s^2 stays finite for very negative a
         const float e = __builtin_amdgcn_exp2f(u);
@@ -158,6 +216,10 @@ template <> struct Frag<bf16> {
     u32x4 v;  // 8 x bf16
     __device__ __forceinline__ void zero() { v = u32x4{0, 0, 0, 0}; }
 };
+template <> struct Frag<f16> {
+    u32x4 v;  // 8 x f16
+    __device__ __forceinline__ void zero() { v = u32x4{0, 0, 0, 0}; }
+};
 template <> struct Frag<float> {
     f32x4 lo, hi;  // 8 x f32
     __device__ __forceinline__ void zero() { lo = f32x4{0, 0, 0, 0}; hi = lo; }
@@ -170,6 +232,9 @@ template <> struct Frag<float> {
 __device__ __forceinline__ void mma16(f32x4& d, const Frag<bf16>& a, const Frag<bf16>& b) {
     d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(mfma_bf16x8, a.v),
                                                 __builtin_bit_cast(mfma_bf16x8, b.v), d, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(f32x4& d, const Frag<f16>& a, const Frag<f16>& b) {
+    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(mfma_f16x8, a.v), __builtin_bit_cast(mfma_f16x8, b.v), d, 0, 0, 0);
 }
 __device__ __forceinline__ void mma16(f32x4& d, const Frag<float>& a, const Frag<float>& b) {
     // exact-f32 MFMA (v_mfma_f32_16x16x4_f32): 8 steps, step j pairs slot j of every lane group.
@@ -185,6 +250,7 @@ __device__ __forceinline__ void mma16(f32x4& d, const Frag<float>& a, const Frag
 
 // load 8 consecutive T elements (16 B for bf16, 32 B for f32) into a fragment
 __device__ __forceinline__ void load_frag(Frag<bf16>& f, const bf16* p) { f.v = *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void load_frag(Frag<f16>& f, const f16* p) { f.v = *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void load_frag(Frag<float>& f, const float* p) {
     f.lo = *reinterpret_cast<const f32x4*>(p);
     f.hi = *reinterpret_cast<const f32x4*>(p + 4);
@@ -195,10 +261,16 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
     u32x2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
     *reinterpret_cast<u32x2*>(p) = o;
 }
+__device__ __forceinline__ void store4(f16* p, f32x4 v) {
+    u32x2 o = {pack2h(v[0], v[1]), pack2h(v[2], v[3])};
+    *reinterpret_cast<u32x2*>(p) = o;
+}
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ void store1(bf16* p, float v) { p->v = f2bf(v); }
+__device__ __forceinline__ void store1(f16* p, float v) { p->v = f2h(v); }
 __device__ __forceinline__ void store1(float* p, float v) { *p = v; }
 __device__ __forceinline__ float load1(const bf16* p) { return bf2f(p->v); }
+__device__ __forceinline__ float load1(const f16* p) { return h2f(p->v); }
 __device__ __forceinline__ float load1(const float* p) { return *p; }
 
 // window-order row m -> flat token index in (B,H,W) for cyclic shift `shift`
@@ -272,7 +344,18 @@ struct ScopedTimer {
         }                                    \
     } while (0)
 
-inline size_t dtype_size(int dt) { return dt == UF_BF16 ? 2 : 4; }
+// run a statement with TT bound to the operand type of `dtype` (checked with dtype_ok beforehand; anything else runs as f32)
+#define UF_DISPATCH(dtype, TT, ...)                                                  \
+    do {                                                                             \
+        if ((dtype) == UF_BF16) { using TT = ::uf::bf16; __VA_ARGS__; }              \
+        else if ((dtype) == UF_F16) { using TT = ::uf::f16; __VA_ARGS__; }           \
+        else { using TT = float; __VA_ARGS__; }                                      \
+    } while (0)
+
+inline size_t dtype_size(int dt) { return (dt == UF_BF16 || dt == UF_F16) ? 2 : 4; }
+inline bool dtype_ok(int dt) { return dt == UF_F32 || dt == UF_BF16 || dt == UF_F16; }
+inline bool dtype_half(int dt) { return dt == UF_BF16 || dt == UF_F16; }
+inline const char* dtype_name(int dt) { return dt == UF_BF16 ? "bf16" : (dt == UF_F16 ? "f16" : "f32"); }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace uf

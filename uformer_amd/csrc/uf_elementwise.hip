@@ -83,18 +83,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // a10: depthwise 3x3 (zero pad 1) + bias + erf-GELU on [B][H][W][C] (LeFF, model.py:659-660).
 // One thread = one pixel x VEC channels (16 bytes of T); fp32 accumulate.
 // ---------------------------------------------------------------------------------------
-template <typename T> struct Vec16;
-template <> struct Vec16<bf16> {
+template <typename T> struct Vec16 {   // the 2-byte operand types (bf16, f16)
+    static_assert(sizeof(T) == 2, "2-byte operand type");
     static constexpr int N = 8;
-    static __device__ __forceinline__ void load(const bf16* p, float* f) {
-        const u32x4 r = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
-    }
-    static __device__ __forceinline__ void store(bf16* p, const float* f) {
-        u32x4 r = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
-        *reinterpret_cast<u32x4*>(p) = r;
-    }
+    static __device__ __forceinline__ void load(const T* p, float* f) { unpack8<T>(*reinterpret_cast<const u32x4*>(p), f); }
+    static __device__ __forceinline__ void store(T* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack8<T>(f); }
 };
 template <> struct Vec16<float> {
     static constexpr int N = 4;
@@ -116,8 +109,7 @@ template <typename T, int N> __device__ __forceinline__ void round_to(float* f) 
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int i = 0; i < N; i += 2) {
-            const unsigned pk = pack2bf(f[i], f[i + 1]);
-            f[i] = __uint_as_float(pk << 16); f[i + 1] = __uint_as_float(pk & 0xffff0000u);
+            unpack2<T>(pack2<T>(f[i], f[i + 1]), f[i], f[i + 1]);
         }
     }
 }
@@ -367,12 +359,8 @@ int launch_layernorm(const float* x, int ld_x, const float* gamma, const float* 
         constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64;                                                              \
         constexpr int RPB = 256 / LPR;                                                                                  \
         dim3 grid((rows + RPB - 1) / RPB);                                                                              \
-        if (dtype == UF_BF16)                                                                                           \
-            hipLaunchKernelGGL((layernorm_kernel<bf16, CV>), grid, dim3(256), 0, st, x, ld_x, gamma, beta, modulator,   \
-                               (bf16*)out, rows, H, W, windowed, shift);                                                \
-        else                                                                                                            \
-            hipLaunchKernelGGL((layernorm_kernel<float, CV>), grid, dim3(256), 0, st, x, ld_x, gamma, beta, modulator,  \
-                               (float*)out, rows, H, W, windowed, shift);                                               \
+        UF_DISPATCH(dtype, TT, hipLaunchKernelGGL((layernorm_kernel<TT, CV>), grid, dim3(256), 0, st, x, ld_x, gamma, beta, modulator, \
+                                                  (TT*)out, rows, H, W, windowed, shift));                               \
         break;                                                                                                          \
     }
     switch (C) {
@@ -435,7 +423,7 @@ extern "C" int uf_pack_weight_fm(const void* w, void* out, int N, int K, uf_dtyp
     const int KS = (K + 31) / 32;
     const long long groups = (long long)(N / 16) * KS * 64;
     dim3 grid((unsigned)((groups + 255) / 256));
-    if (dtype == UF_BF16) hipLaunchKernelGGL(pack_fm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)out, N, K, KS);
+    if (dtype_half(dtype)) hipLaunchKernelGGL(pack_fm_kernel<uint16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t*)w, (uint16_t*)out, N, K, KS);
     else if (dtype == UF_F32) hipLaunchKernelGGL(pack_fm_kernel<uint32_t>, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)w, (uint32_t*)out, N, K, KS);
     else { set_error("uf_pack_weight_fm: dtype %d", (int)dtype); return UF_ERR_UNSUPPORTED; }
     return check_launch("pack_weight_fm");
@@ -454,7 +442,7 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
     UF_REQUIRE(B > 0 && H > 0 && W > 0, UF_ERR_SHAPE, "uf_layernorm_fwd: B=%d H=%d W=%d", B, H, W);
     UF_REQUIRE(!windowed || (H % 8 == 0 && W % 8 == 0), UF_ERR_SHAPE, "uf_layernorm_fwd: windowed needs H,W multiples of 8");
     UF_REQUIRE(ld_x >= C && ld_x % 4 == 0, UF_ERR_ALIGN, "uf_layernorm_fwd: ld_x=%d", ld_x);
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_layernorm_fwd: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_layernorm_fwd: dtype %d", (int)dtype);
     return launch_layernorm(x, ld_x, gamma, beta, modulator, out, B * H * W, H, W, C, windowed, shift, dtype, (hipStream_t)stream);
 }
 
@@ -472,28 +460,21 @@ void launch_dwconv(const void* x, const float* w9, const float* bias, void* out,
 int dwconv_any(const char* fn, const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, int mode, uf_dtype dtype, void* stream) {
     UF_REQUIRE(x && w9 && out && (bias || mode == 0 || mode == 3) && (aux || mode < 2), UF_ERR_NULL, "%s: null pointer", fn);
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "%s: bad shape (H must be a multiple of %d)", fn, DW_R);
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
-    UF_REQUIRE(C % (dtype == UF_BF16 ? 8 : 4) == 0, UF_ERR_SHAPE, "%s: C=%d must be a multiple of %d", fn, C, dtype == UF_BF16 ? 8 : 4);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
+    UF_REQUIRE(C % (dtype_half(dtype) ? 8 : 4) == 0, UF_ERR_SHAPE, "%s: C=%d must be a multiple of %d", fn, C, dtype_half(dtype) ? 8 : 4);
     UF_REQUIRE(((uintptr_t)w9 % 16) == 0 && (!bias || ((uintptr_t)bias % 16) == 0), UF_ERR_ALIGN, "%s: w9 / bias must be 16-byte aligned", fn);
     hipStream_t st = (hipStream_t)stream;
     char tname[64] = "";
     if (timing_enabled()) snprintf(tname, sizeof(tname), "dwconv3x3_m%d %dx%d", mode, B * H * W, C);
     ScopedTimer tm(tname, 18.0 * B * H * W * C, (mode >= 2 ? 3.0 : 2.0) * B * H * W * C * dtype_size(dtype), st);
-    if (dtype == UF_BF16) {
+    UF_DISPATCH(dtype, TT, {
         switch (mode) {
-            case 0: launch_dwconv<bf16, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            case 1: launch_dwconv<bf16, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            case 2: launch_dwconv<bf16, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            default: launch_dwconv<bf16, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 0: launch_dwconv<TT, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 1: launch_dwconv<TT, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 2: launch_dwconv<TT, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            default: launch_dwconv<TT, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
         }
-    } else {
-        switch (mode) {
-            case 0: launch_dwconv<float, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            case 1: launch_dwconv<float, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            case 2: launch_dwconv<float, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
-            default: launch_dwconv<float, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
-        }
-    }
+    });
     return check_launch("dwconv3x3");
 }
 }  // namespace

@@ -55,8 +55,8 @@ struct AChunk {
     __device__ __forceinline__ u32x4 finish() const {
         u32x4 v = lo;
         if constexpr (WIDE) {
-            v = u32x4{pack2bf(__uint_as_float(lo[0]), __uint_as_float(lo[1])), pack2bf(__uint_as_float(lo[2]), __uint_as_float(lo[3])),
-                      pack2bf(__uint_as_float(hi[0]), __uint_as_float(hi[1])), pack2bf(__uint_as_float(hi[2]), __uint_as_float(hi[3]))};
+            v = u32x4{pack2<T>(__uint_as_float(lo[0]), __uint_as_float(lo[1])), pack2<T>(__uint_as_float(lo[2]), __uint_as_float(lo[3])),
+                      pack2<T>(__uint_as_float(hi[0]), __uint_as_float(hi[1])), pack2<T>(__uint_as_float(hi[2]), __uint_as_float(hi[3]))};
         }
         return ok ? v : u32x4{0, 0, 0, 0};
     }
@@ -76,15 +76,14 @@ struct WChunk {
 
 template <typename T> __device__ __forceinline__ void unpack_chunk(u32x4 v, float* f) {
     if constexpr (sizeof(T) == 2) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(v[i] << 16); f[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+        unpack8<T>(v, f);
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) f[i] = __uint_as_float(v[i]);
     }
 }
 template <typename T> __device__ __forceinline__ u32x4 pack_chunk(const float* f) {
-    if constexpr (sizeof(T) == 2) return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+    if constexpr (sizeof(T) == 2) return pack8<T>(f);
     else return u32x4{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
 }
 
@@ -335,7 +334,7 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d %dx%dx%d", sizeof(T) == 2 ? "bf16" : "f32", BN, AL, EP, p.M, p.N, p.K);
+        snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d %dx%dx%d", TypeName<T>::s, BN, AL, EP, p.M, p.N, p.K);
     const double sz = sizeof(T), mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     const double a_bytes = AL == A_PLAIN ? mk * sz : (AL == A_FROM_R ? mk * 4 : mk);  // conv-down reads each input once
     const double o_bytes = (EP == E_RES || EP == E_RES_WINREV) ? mn * 8 : ((EP == E_STORE_R || EP == E_UPSAMPLE) ? mn * 4 : mn * sz);
@@ -382,7 +381,7 @@ int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
 }  // namespace
 
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream) {
-    const int epc = dtype == UF_BF16 ? 8 : 4;
+    const int epc = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, UF_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     UF_REQUIRE(p.K % epc == 0 && p.N % 4 == 0, UF_ERR_SHAPE, "gemm: K=%d must be a multiple of %d and N=%d of 4", p.K, epc, p.N);
     UF_REQUIRE(p.A && p.W && p.bias, UF_ERR_NULL, "gemm: null operand");
@@ -399,6 +398,7 @@ int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStre
     }
     if (aload == A_CONV_DOWN) UF_REQUIRE(p.C % 8 == 0, UF_ERR_SHAPE, "downsample: C=%d must be a multiple of 8", p.C);
     if (dtype == UF_BF16) return launch_t<bf16>(p, aload, epi, stream);
+    if (dtype == UF_F16) return launch_t<f16>(p, aload, epi, stream);
     if (dtype == UF_F32) return launch_t<float>(p, aload, epi, stream);
     set_error("gemm: unknown dtype %d", (int)dtype);
     return UF_ERR_UNSUPPORTED;

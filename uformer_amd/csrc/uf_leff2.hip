@@ -31,18 +31,14 @@ struct Leff2Params {
 constexpr int KCW = 64;  // hidden channels one producer group (4 waves) convolves per interval
 
 template <typename T> __device__ __forceinline__ void cvt8(const char* p, float* f);
-template <> __device__ __forceinline__ void cvt8<bf16>(const char* p, float* f) {
-    const u32x4 r = *reinterpret_cast<const u32x4*>(p);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(r[i] << 16); f[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u); }
-}
+template <> __device__ __forceinline__ void cvt8<bf16>(const char* p, float* f) { unpack8<bf16>(*reinterpret_cast<const u32x4*>(p), f); }
+template <> __device__ __forceinline__ void cvt8<f16>(const char* p, float* f) { unpack8<f16>(*reinterpret_cast<const u32x4*>(p), f); }
 template <> __device__ __forceinline__ void cvt8<float>(const char* p, float* f) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 16);
     f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
 }
-__device__ __forceinline__ void put8(bf16* p, const float* f) {
-    *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
-}
+__device__ __forceinline__ void put8(bf16* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack8<bf16>(f); }
+__device__ __forceinline__ void put8(f16* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack8<f16>(f); }
 __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
@@ -325,7 +321,7 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "leff2")) return rc;
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", SZ == 2 ? "bf16" : "f32", C, 4 * NPG, NC, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", TypeName<T>::s, C, 4 * NPG, NC, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
         hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((4 * NPG + NC) * 64), smem, st, p);
@@ -393,6 +389,7 @@ int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* 
     p.tbuf = debug_get_tbuf();
     p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W; p.drop = drop;
     if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
+    if (dtype == UF_F16) return launch_t<f16>(p, C, st);
     if (dtype == UF_F32) return launch_t<float>(p, C, st);
     set_error("uf_dwconv_linear2_fwd: dtype %d", (int)dtype);
     return UF_ERR_UNSUPPORTED;

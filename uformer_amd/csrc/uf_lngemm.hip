@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, 2) void ln_gemm_kernel(const LnGemmParams p) {
                 for (int ip = 0; ip < 4; ip += 2) {              // tile pair (ip, ip+1)
                     f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
                     gelu4<T>(va); gelu4<T>(vb);
-                    const unsigned a0 = pack2bf(va[0], va[1]), a1 = pack2bf(va[2], va[3]);
-                    const unsigned b0 = pack2bf(vb[0], vb[1]), b1 = pack2bf(vb[2], vb[3]);
+                    const unsigned a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
+                    const unsigned b0 = pack2<T>(vb[0], vb[1]), b1 = pack2<T>(vb[2], vb[3]);
                     // after the swap: even fg lanes hold 8 channels of tile ip, odd fg lanes 8 channels of tile ip+1
                     const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
@@ -340,7 +340,7 @@ int launch_one(const LnGemmParams& p_in, hipStream_t st) {
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "ln_gemm")) return rc;
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "ln_gemm_%s_%s_c%d_bm%d %dx%dx%d", SZ == 2 ? "bf16" : "f32", EP == EP_QKV ? "qkv" : "fc1", C, BM, p.M, p.N, C);
+        snprintf(name, sizeof(name), "ln_gemm_%s_%s_c%d_bm%d %dx%dx%d", TypeName<T>::s, EP == EP_QKV ? "qkv" : "fc1", C, BM, p.M, p.N, C);
     const double mn = (double)p.M * p.N;
     {
         ScopedTimer tm(name, 2.0 * mn * C, (double)p.M * C * 4 + (double)p.N * C * SZ + mn * SZ, st);
@@ -386,7 +386,7 @@ int check_common(const float* x, int ld, const float* g, const float* b, const v
     UF_REQUIRE(!windowed || (H % 8 == 0 && W % 8 == 0), UF_ERR_SHAPE, "ln_gemm: windowed needs H,W multiples of 8");
     UF_REQUIRE(ld >= C && ld % 4 == 0, UF_ERR_ALIGN, "ln_gemm: ld=%d", ld);
     UF_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)bias % 16) == 0, UF_ERR_ALIGN, "ln_gemm: operands must be 16-byte aligned");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "ln_gemm: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "ln_gemm: dtype %d", (int)dtype);
     return UF_OK;
 }
 
@@ -410,7 +410,9 @@ extern "C" int uf_ln_qkv_fwd(const float* x, int ld, const float* gamma, const f
     p.M = B * H * W; p.N = 3 * C; p.H = H; p.W = W; p.windowed = 1; p.shift = shift;
     p.q = q; p.k = k; p.vt = vt; p.heads = heads; p.hd = hd; p.qscale = (float)(1.0 / sqrt((double)hd));
     hipStream_t st = (hipStream_t)stream;
-    return dtype == UF_BF16 ? launch_c<bf16, EP_QKV>(p, C, st) : launch_c<float, EP_QKV>(p, C, st);
+    if (dtype == UF_BF16) return launch_c<bf16, EP_QKV>(p, C, st);
+    if (dtype == UF_F16) return launch_c<f16, EP_QKV>(p, C, st);
+    return launch_c<float, EP_QKV>(p, C, st);
 }
 
 extern "C" int uf_ln_linear_gelu_fwd(const float* x, int ld, const float* gamma, const float* beta, const void* W1,
@@ -418,10 +420,12 @@ extern "C" int uf_ln_linear_gelu_fwd(const float* x, int ld, const float* gamma,
     int rc = check_common(x, ld, gamma, beta, W1, b1, 1, 1, M > 0 ? M : 1, C, 0, dtype);
     if (rc) return rc;
     UF_REQUIRE(out && M > 0 && N > 0, UF_ERR_NULL, "uf_ln_linear_gelu_fwd: bad output / shape");
-    UF_REQUIRE(N % (dtype == UF_BF16 ? 8 : 4) == 0, UF_ERR_SHAPE, "uf_ln_linear_gelu_fwd: N=%d", N);
+    UF_REQUIRE(N % (dtype_half(dtype) ? 8 : 4) == 0, UF_ERR_SHAPE, "uf_ln_linear_gelu_fwd: N=%d", N);
     LnGemmParams p{};
     p.x = x; p.ld = ld; p.gamma = gamma; p.beta = beta; p.modulator = nullptr; p.Wt = W1; p.bias = b1;
     p.M = M; p.N = N; p.H = 1; p.W = M; p.windowed = 0; p.shift = 0; p.out = out; p.ldo = N;
     hipStream_t st = (hipStream_t)stream;
-    return dtype == UF_BF16 ? launch_c<bf16, EP_GELU>(p, C, st) : launch_c<float, EP_GELU>(p, C, st);
+    if (dtype == UF_BF16) return launch_c<bf16, EP_GELU>(p, C, st);
+    if (dtype == UF_F16) return launch_c<f16, EP_GELU>(p, C, st);
+    return launch_c<float, EP_GELU>(p, C, st);
 }

@@ -41,7 +41,7 @@ int carve(BlockWs& w, void* ws, size_t ws_bytes, size_t M, size_t C, uf_dtype dt
 
 int check_block_args(const uf_block_params* p, const float* x, int ld, int B, int H, int W, int C, uf_dtype dtype) {
     UF_REQUIRE(p && x, UF_ERR_NULL, "block: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "block: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "block: dtype %d", (int)dtype);
     UF_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, UF_ERR_SHAPE, "block: B=%d H=%d W=%d (H,W multiples of 8)", B, H, W);
     UF_REQUIRE(C >= 16 && C % 16 == 0 && ld >= C && ld % 4 == 0, UF_ERR_SHAPE, "block: C=%d ld=%d", C, ld);
     UF_REQUIRE(p->heads > 0 && C % p->heads == 0, UF_ERR_SHAPE, "block: C=%d heads=%d", C, p->heads);
@@ -61,11 +61,11 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
     static const bool no_fc1 = getenv("UF_NO_FC1_FUSION") != nullptr;
     if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) {
-        const bool with_fc1 = fc1_done && !no_fc1 && dtype == UF_BF16 && C >= 32;
+        const bool with_fc1 = fc1_done && !no_fc1 && dtype_half(dtype) && C >= 32;
         if (fc1_done) *fc1_done = with_fc1;
         return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st, drop);
     }
-    UF_REQUIRE(!drop, UF_ERR_UNSUPPORTED, "DropPath scales need the fused attention kernel (bf16, or f32 with C <= 256; no caller mask)");
+    UF_REQUIRE(!drop, UF_ERR_UNSUPPORTED, "DropPath scales need the fused attention kernel (bf16 / f16, or f32 with C <= 256; no caller mask)");
     // LN1 -> roll -> partition -> + modulator -> q,k,v projections, one kernel
     // (model.py:952-969, :431-442, :497)
     char* q = w.h1;
@@ -255,10 +255,26 @@ int forward_one_stream(const uf_model_desc* d, const float* img, float* out, int
         ld = 2 * pl.C[s];
     };
     const uf_block_params* blk = d->blocks;
+    // Image chunks (UF_CHUNK_MB = working-set target in MiB, 0 = off): a block's two kernels run chunk by chunk -- attn_block(chunk) then
+    // leff2(chunk) -- so that the 4C-wide hidden tensor h1 one writes and the other reads (half of a block's HBM bytes at C <= 128) and the
+    // chunk's stream rows stay inside the 256 MiB Infinity Cache instead of making a round trip through HBM; every chunk reuses the same
+    // scratch.  Images never interact inside a block, so the results are bit-identical to the whole-batch launches.
+    static const long long chunk_mb = getenv("UF_CHUNK_MB") ? atoll(getenv("UF_CHUNK_MB")) : 0;
     auto run_stage = [&](int s, float* x, int ld) -> int {
+        const size_t per_img = (size_t)pl.res[s] * pl.res[s] * pl.C[s] * (4 * dtype_size(dtype) + 2 * sizeof(float));   // h1 + the stream rows in and out
+        int cb = B;
+        if (chunk_mb > 0) {
+            const long long fit = (long long)((size_t)chunk_mb * 1024 * 1024 / per_img);
+            cb = fit < 1 ? 1 : (fit > B ? B : (int)fit);
+            if ((long long)cb * (pl.res[s] / 8) * (pl.res[s] / 8) < 1024) cb = B;     // never starve the chip: a chunk keeps >= 1024 workgroups
+        }
         for (int i = 0; i < d->depths[s]; ++i, ++blk) {
-            int r = uf_lewin_block_fwd(blk, x, ld, B, pl.res[s], pl.res[s], pl.C[s], nullptr, 0, dtype, bws, pl.blk_bytes, st);
-            if (r) return r;
+            for (int b0 = 0; b0 < B; b0 += cb) {
+                const int bn = B - b0 < cb ? B - b0 : cb;
+                int r = uf_lewin_block_fwd(blk, x + (size_t)b0 * pl.res[s] * pl.res[s] * ld, ld, bn, pl.res[s], pl.res[s], pl.C[s], nullptr, 0, dtype, bws,
+                                           pl.blk_bytes, st);
+                if (r) return r;
+            }
         }
         return UF_OK;
     };

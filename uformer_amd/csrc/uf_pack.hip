@@ -10,10 +10,7 @@
 namespace uf {
 namespace {
 
-template <typename T> __device__ __forceinline__ void store8_t(T* p, const float* f);
-template <> __device__ __forceinline__ void store8_t<bf16>(bf16* p, const float* f) {
-    *reinterpret_cast<u32x4*>(p) = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
-}
+template <typename T> __device__ __forceinline__ void store8_t(T* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack8<T>(f); }   // 2-byte types
 template <> __device__ __forceinline__ void store8_t<float>(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
@@ -99,14 +96,14 @@ void launch_pack_linear(const float* s0, int n0, const float* s1, int N, int K, 
 using namespace uf;
 
 extern "C" size_t uf_pack_block_train_bytes(int C, int heads, uf_dtype dtype) {
-    if (C <= 0 || heads <= 0 || (dtype != UF_BF16 && dtype != UF_F32)) return 0;
+    if (C <= 0 || heads <= 0 || !dtype_ok(dtype)) return 0;
     return plan_pack(C, heads, dtype).total;
 }
 
 extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int heads, int shift, uf_dtype dtype, void* buf, size_t buf_bytes,
                                    uf_block_params* fwd, uf_block_train_params* bwd, void* stream) {
     UF_REQUIRE(raw && buf && (fwd || bwd), UF_ERR_NULL, "uf_pack_block_train: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_pack_block_train: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_pack_block_train: dtype %d", (int)dtype);
     UF_REQUIRE(C >= 32 && C % 32 == 0 && heads > 0 && C % heads == 0, UF_ERR_SHAPE, "uf_pack_block_train: C=%d heads=%d (C a multiple of 32)", C, heads);
     UF_REQUIRE(raw->norm1_w && raw->norm1_b && raw->norm2_w && raw->norm2_b && raw->rpb_table && raw->rpb_index && raw->to_q_w && raw->to_q_b && raw->to_kv_w &&
                    raw->to_kv_b && raw->proj_w && raw->proj_b && raw->lin1_w && raw->lin1_b && raw->dw_w && raw->dw_b && raw->lin2_w && raw->lin2_b,
@@ -116,17 +113,12 @@ extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int he
     hipStream_t st = (hipStream_t)stream;
     char* b = (char*)buf;
     auto at = [&](size_t o) { return (void*)(b + o); };
-    if (dtype == UF_BF16) {
-        launch_pack_linear<bf16>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
-        launch_pack_linear<bf16>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
-        launch_pack_linear<bf16>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
-        launch_pack_linear<bf16>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
-    } else {
-        launch_pack_linear<float>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
-        launch_pack_linear<float>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
-        launch_pack_linear<float>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
-        launch_pack_linear<float>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
-    }
+    UF_DISPATCH(dtype, TT, {
+        launch_pack_linear<TT>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
+        launch_pack_linear<TT>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
+        launch_pack_linear<TT>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
+        launch_pack_linear<TT>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
+    });
     SmallPack sp{raw->to_q_b, raw->to_kv_b, raw->dw_w, raw->rpb_table, (const long long*)raw->rpb_index,
                  (float*)at(pl.bqkv), (float*)at(pl.w9), (float*)at(pl.w9_flip), (float*)at(pl.dense), (float*)at(pl.tab), C, heads};
     const int n_small = 3 * C + 72 * C + heads * (4096 + 225);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void taps_to_param_kernel(const float* __restr
 
 int check_common(const char* fn, const uf_block_train_params* p, const uf_block_grads* g, int B, int H, int W, int C, uf_dtype dtype, const void* ws, size_t ws_bytes) {
     UF_REQUIRE(p && g && ws, UF_ERR_NULL, "%s: null pointer", fn);
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "%s: dtype %d", fn, (int)dtype);
     UF_REQUIRE(B > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0 && C >= 32 && C % 32 == 0 && p->heads * 32 == C, UF_ERR_SHAPE,
                "%s: B=%d H=%d W=%d C=%d heads=%d (H, W multiples of 8; head_dim 32)", fn, B, H, W, C, p->heads);
     UF_REQUIRE(p->shift == 0 || p->shift == 4, UF_ERR_UNSUPPORTED, "%s: shift %d", fn, p->shift);
@@ -214,7 +214,7 @@ int zero_bias(const BlockPlan& pl, int C, void* st) {
 using namespace uf;
 
 extern "C" size_t uf_lewin_block_bwd_workspace_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype) {
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || (dtype != UF_BF16 && dtype != UF_F32)) return 0;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || heads <= 0 || !dtype_ok(dtype)) return 0;
     return plan_block(nullptr, B, H, W, C, heads, dtype).total;
 }
 
@@ -284,7 +284,7 @@ extern "C" size_t uf_downsample_bwd_workspace_bytes(int B, int H, int W, int Cin
 extern "C" int uf_downsample_bwd(const float* x, int ld_x, const float* dy, const void* w_pk_t, float* dx, int ld_dx, int accumulate, float* dW_pk, float* db,
                                  int B, int H, int W, int Cin, int Cout, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(x && dy && w_pk_t && dx && dW_pk && db && ws, UF_ERR_NULL, "uf_downsample_bwd: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_downsample_bwd: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_downsample_bwd: dtype %d", (int)dtype);
     UF_REQUIRE(B > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0 && Cin % 8 == 0 && Cout % 8 == 0 && ld_x >= Cin && ld_dx >= Cin, UF_ERR_SHAPE,
                "uf_downsample_bwd: B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     const size_t need = uf_downsample_bwd_workspace_bytes(B, H, W, Cin, Cout, dtype);
@@ -324,7 +324,7 @@ extern "C" size_t uf_upsample_cat_bwd_workspace_bytes(int B, int H, int W, int C
 extern "C" int uf_upsample_cat_bwd(const float* d, int ld_d, const float* x, int ld_x, const void* w_pk_t, float* dx, float* dW_pk, float* db,
                                    int B, int H, int W, int Cin, int Cout, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
     UF_REQUIRE(d && x && w_pk_t && dx && dW_pk && db && ws, UF_ERR_NULL, "uf_upsample_cat_bwd: null pointer");
-    UF_REQUIRE(dtype == UF_BF16 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_upsample_cat_bwd: dtype %d", (int)dtype);
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_upsample_cat_bwd: dtype %d", (int)dtype);
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 8 == 0 && Cout % 8 == 0 && ld_d >= Cout && ld_x == Cin, UF_ERR_SHAPE,
                "uf_upsample_cat_bwd: B=%d H=%d W=%d Cin=%d Cout=%d ld_d=%d ld_x=%d (x rows must be dense)", B, H, W, Cin, Cout, ld_d, ld_x);
     const size_t need = uf_upsample_cat_bwd_workspace_bytes(B, H, W, Cin, Cout, dtype);

@@ -11,23 +11,25 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import UF_BF16, UF_F32, UformerHipError
+from ._lib import UF_BF16, UF_F16, UF_F32, UformerHipError
 
 Tensor = torch.Tensor
 
 
 def uf_dtype(dtype) -> int:
-    if dtype in (UF_F32, UF_BF16) and not isinstance(dtype, torch.dtype):
+    if dtype in (UF_F32, UF_BF16, UF_F16) and not isinstance(dtype, torch.dtype):
         return int(dtype)
     if dtype == torch.float32:
         return UF_F32
     if dtype == torch.bfloat16:
         return UF_BF16
-    raise UformerHipError(f"unsupported operand dtype {dtype} (torch.float32 or torch.bfloat16)")
+    if dtype == torch.float16:
+        return UF_F16
+    raise UformerHipError(f"unsupported operand dtype {dtype} (torch.float32, torch.bfloat16 or torch.float16)")
 
 
 def torch_dtype(dt: int) -> torch.dtype:
-    return torch.bfloat16 if dt == UF_BF16 else torch.float32
+    return {UF_BF16: torch.bfloat16, UF_F16: torch.float16}.get(dt, torch.float32)
 
 
 def _dev(*ts: Tensor) -> torch.device:

@@ -288,7 +288,7 @@ class UformerTape:
     def __init__(self, sd: Dict[str, Tensor], cfg, dtype: torch.dtype = torch.float32, drop_scales: Optional[Tensor] = None,
                  recompute: Optional[bool] = None, on_stage_done=None):
         self.sd, self.cfg, self.T, self.drop = sd, cfg, dtype, drop_scales
-        self.recompute = (dtype == torch.bfloat16) if recompute is None else recompute
+        self.recompute = (dtype in (torch.bfloat16, torch.float16)) if recompute is None else recompute
         self.on_stage_done = on_stage_done          # callback({name: gradient}) for every group of parameters whose gradients are final, in reverse-sweep order
 
     def forward(self, img: Tensor) -> Tensor:
@@ -418,12 +418,19 @@ class UformerTape:
 
 
 def uformer_forward_backward(img: Tensor, sd: Dict[str, Tensor], dy: Tensor, *, cfg, dtype: torch.dtype = torch.float32,
-                             drop_scales: Optional[Tensor] = None, recompute: Optional[bool] = None) -> Tuple[Tensor, Tensor, Grads]:
+                             drop_scales: Optional[Tensor] = None, recompute: Optional[bool] = None, loss_scale: float = 1.0) -> Tuple[Tensor, Tensor, Grads]:
     """Whole-model forward + backward.  img, dy: (B,3,H,W) f32 on the GPU; sd: the reference state_dict on the GPU; cfg:
-    uformer_amd.spec.UformerConfig.  Returns (y, d img, parameter gradients keyed like named_parameters())."""
+    uformer_amd.spec.UformerConfig.  Returns (y, d img, parameter gradients keyed like named_parameters()).
+    ``loss_scale`` (float16 operands): the reverse sweep runs on ``dy * loss_scale`` and the results are divided by it, what
+    torch.cuda.amp.GradScaler does around the reference's backward (train/train_denoise.py:180-184): activation gradients travel as
+    f16 operands, and d loss / d y of a mean loss over millions of pixels is below f16's smallest normal number (6.1e-5)."""
     tape = UformerTape(sd, cfg, dtype, drop_scales, recompute)
     y = tape.forward(img)
-    dimg, g = tape.backward(dy)
+    dimg, g = tape.backward(dy * loss_scale if loss_scale != 1.0 else dy)
+    if loss_scale != 1.0:
+        inv = 1.0 / loss_scale
+        dimg = dimg * inv
+        g = {k: v * inv for k, v in g.items()}
     return y, dimg, g
 
 
