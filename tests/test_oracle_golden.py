@@ -302,3 +302,75 @@ def test_expand2square_matches_reference_digest(golden):
     xp, msk = O.expand2square(spec.synth_input(1, 720, 1280, 9), 128.0)
     assert hashlib.sha256(xp.numpy().tobytes()).hexdigest() == str(g["x_sha256"])
     assert float(msk.sum()) == float(g["mask_sum"]) == 720 * 1280
+
+
+# ---- rows f-3 / f-4: the oracle helpers either side of the path, pinned to the reference's own code (tests/golden/make_golden_tail.py)
+def test_tail_psnr_pinned_to_reference(golden):
+    """O.psnr / O.batch_psnr vs the reference's myPSNR / batch_PSNR (utils/image_utils.py:40-51, ast-compiled)."""
+    g = golden("tail_psnr")
+    a, b = t(g["a"]), t(g["b"])
+    for i in range(a.shape[0]):
+        assert abs(O.psnr(a[i], b[i]) - float(g["per_image"][i])) < 1e-4
+    assert abs(O.psnr(a, b) - float(g["whole"])) < 1e-4
+    assert abs(O.batch_psnr(a, b, True) - float(g["avg"])) < 1e-4
+    assert abs(O.batch_psnr(a, b, False) - float(g["total"])) < 1e-3
+
+
+def test_tail_augment_and_mixup_pinned_to_reference(golden):
+    """O.augment / O.crop_augment vs all 8 Augment_RGB_torch transforms, O.mixup vs MixUp_AUG.aug with its recorded draws
+    (utils/dataset_utils.py:5-49, ast-compiled): bit-exact (pure index work; the mix is two f32 multiplies and an add)."""
+    g = golden("tail_augment")
+    x, frame = t(g["x"]), t(g["frame"])
+    r, c, ps = int(g["crop_r"]), int(g["crop_c"]), int(g["crop_ps"])
+    for k in range(8):
+        assert torch.equal(O.augment(x, k), t(g[f"t{k}"])), k
+        assert torch.equal(O.crop_augment(frame, r, c, ps, k), t(g[f"crop_t{k}"])), k
+    perm, lam = t(g["mix_perm"]), t(g["mix_lam"])
+    assert torch.equal(O.mixup(t(g["mix_gt"]), lam, perm), t(g["mix_gt_out"]))
+    assert torch.equal(O.mixup(t(g["mix_noisy"]), lam, perm), t(g["mix_noisy_out"]))
+    assert 0.0 < float(lam.min()) and float(lam.max()) < 1.0            # Beta(1.2, 1.2) draws
+
+
+def test_tail_checkpoint_read_by_the_reference_loader(golden, tmp_path):
+    """uformer_amd.checkpoint writes the dict the reference's load_checkpoint / load_optim / load_start_epoch read
+    (utils/model_utils.py:23-54): the fixture holds the digests of what the REFERENCE's model and optimizer contained after loading
+    the file this test rebuilds (same code, same seeds); plain and 'module.'-prefixed forms."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    g = golden("tail_checkpoint")
+    # the fixture script's own helpers, minus everything that touches /root/reference
+    import ast
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_golden_tail.py")).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("sd_digest", "optim_digest", "write_reference_style_checkpoint")]
+    ns = {"torch": torch, "hashlib": hashlib, "spec": spec}
+    exec(compile(ast.Module(body=body, type_ignores=[]), "make_golden_tail.py", "exec"), ns)
+    from uformer_amd import checkpoint as ck
+    from uformer_amd import model as um
+    for prefix, tag in ((False, "plain."), (True, "dp.")):
+        path = str(tmp_path / f"ck_{int(prefix)}.pth")
+        cfg, ours, opt = ns["write_reference_style_checkpoint"](path, prefix)
+        raw = torch.load(path, map_location="cpu")
+        assert set(raw) == {"epoch", "state_dict", "optimizer"}                      # train/train_denoise.py:207-210
+        assert all(k.startswith("module.") for k in raw["state_dict"]) == prefix
+        assert ns["sd_digest"](ours.state_dict()) == str(g[tag + "state_digest"])    # what the reference's model held after load_checkpoint
+        assert len(ours.state_dict()) == int(g[tag + "n_keys"])
+        assert ck.load_start_epoch(path) == int(g[tag + "epoch"]) == 17
+        m2 = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
+                        dd_in=cfg.dd_in, compute_dtype=torch.float32)
+        ck.load_checkpoint(m2, path)
+        assert ns["sd_digest"](m2.state_dict()) == str(g[tag + "state_digest"])
+        o2 = torch.optim.AdamW(m2.parameters(), lr=9.9)
+        assert abs(ck.load_optim(o2, path) - float(g[tag + "lr"])) < 1e-12
+        assert ns["optim_digest"](o2.state_dict()) == str(g[tag + "optim_digest"])  # = the reference's optimizer after load_optim
+
+
+def test_tail_ssim_against_second_restatement(golden):
+    """O.ssim (scipy valid correlation) vs an independent separable float64 restatement of utils/caculate_psnr_ssim.py:35-81.
+    cv2 is not installed in the build container (recorded in the fixture), so this row stays 'restated', not reference-run."""
+    g = golden("tail_ssim")
+    assert int(g["cv2_available"]) == 0 and str(g["pinned_by"]) == "restatement"
+    a, b = t(g["a"]), t(g["b"])
+    for i in range(a.shape[0]):
+        assert abs(O.ssim(a[i], b[i]) - float(g["ssim"][i])) < 1e-9
