@@ -47,11 +47,23 @@ def check_grad_B(g, loss: float, y: torch.Tensor, dx: torch.Tensor, grads: dict,
     assert (torch.nn.functional.avg_pool2d(dx, 16) - pref).abs().max().item() <= rtol * max(pref.abs().max().item(), dref.abs().max().item() / 16)
     names = [str(n) for n in g["param_names"]]
     assert sorted(names) == sorted(k for k in grads), "parameter set differs from the reference's named_parameters()"
+    return check_param_grads(g, grads, rtol, min_blocks=40)
+
+
+def check_param_grads(g, grads: dict, rtol: float, min_blocks: int):
+    """Every parameter gradient against the probes a fixture generator stored (tests/gradproj.py): two signed random projections
+    (tolerance rtol * ||g_ref||_2), a seeded 4096-element gather or the full tensor (rtol * max|g_ref|) and 64x64 blocks of one
+    parameter per kind and stage.  A gradient that is None counts as zeros (a block DropPath removed for every sample)."""
+    names = [str(n) for n in g["param_names"]]
+    assert sorted(names) == sorted(k for k in grads), "parameter set differs from the reference's named_parameters()"
     worst = {"proj": 0.0, "elem": 0.0, "block": 0.0}
     nfull = ngather = nblock = 0
     for i, n in enumerate(names):
         gr = grads[n]
-        assert gr is not None, n
+        l2ref = float(g["norms"][i, 0])
+        assert gr is not None or l2ref == 0.0, n
+        if gr is None:
+            continue
         gr = gr.detach().float().cpu()
         l2, mx = float(g["norms"][i, 0]), float(g["norms"][i, 1])
         for k in range(2):
@@ -71,5 +83,20 @@ def check_grad_B(g, loss: float, y: torch.Tensor, dx: torch.Tensor, grads: dict,
             dev = (gr.reshape(gr.shape[0], -1)[:64, :64] - ref).abs().max().item() / max(mx, 1e-30)
             assert dev <= rtol, f"{n}: 64x64 block off by {dev:.3e} x max|g|"
             worst["block"] = max(worst["block"], dev)
-    assert nfull + ngather == len(names) and nblock >= 40
+    assert nblock >= min_blocks
+    return worst
+
+
+def check_grad_T(g, loss: float, y: torch.Tensor, dx: torch.Tensor, grads: dict, *, rtol: float, loss_tol: float, y_tol: float):
+    """tests/golden/grad_model_T_128.npz (Uformer_T = head_dim 16, train mode, recorded DropPath masks): loss, restored images, d loss /
+    d input and every parameter gradient (check_param_grads)."""
+    assert abs(loss - float(g["loss"])) <= loss_tol, (loss, float(g["loss"]))
+    y, dx = y.float().cpu(), dx.float().cpu()
+    ey = (y - _t(g["y"])).abs().max().item()
+    assert ey <= y_tol, f"restored images off by {ey:.3e} (tol {y_tol})"
+    dref = _t(g["dx"])
+    ed = (dx - dref).abs().max().item() / dref.abs().max().item()
+    assert ed <= rtol, f"d loss / d input off by {ed:.3e} x max (tol {rtol})"
+    worst = check_param_grads(g, grads, rtol, min_blocks=20)
+    worst.update(y=ey, dx=ed)
     return worst

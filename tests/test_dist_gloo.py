@@ -112,7 +112,7 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     assert err < 1e-4 and err3 < 1e-5 and nb > 3
 
 
-def _overlap_worker(rank, world, port, q):
+def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None):
     """OverlappedGradientAllReduce driven the way UformerTape.backward drives it: gradients arrive stage by stage in reverse-sweep
     order (head, decoder 3..0, bottleneck, encoder 3..0, stem), every bucket is reduced the moment its last gradient is in, p.grad
     is a view of the bucket, and the average is folded into the optimizer's grad_scale."""
@@ -126,7 +126,6 @@ def _overlap_worker(rank, world, port, q):
     ud.init_process_group("gloo")
     cfg = spec.arch_config("tiny", 128)
     kw = dict(img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
-    gb = 2
     x, tgt = spec.synth_input(gb, 128, 128, 6), spec.synth_input(gb, 128, 128, 7)
 
     def grads_of(xs, ts, weight):
@@ -142,24 +141,40 @@ def _overlap_worker(rank, world, port, q):
     stages = ["output_proj", "decoderlayer_3", "upsample_3", "decoderlayer_2", "upsample_2", "decoderlayer_1", "upsample_1", "decoderlayer_0", "upsample_0",
               "conv", "dowsample_3", "encoderlayer_3", "dowsample_2", "encoderlayer_2", "dowsample_1", "encoderlayer_1", "dowsample_0", "encoderlayer_0",
               "input_proj"]
-    dropped = "encoderlayer_2.blocks.0.mlp.linear1.0.weight"
+    # gradients DropPath removed locally: different sets on different ranks (uneven masks) -- the collectives must still be identical
+    dropped_by_rank = dropped_by_rank or {1: ["encoderlayer_2.blocks.0.mlp.linear1.0.weight"]}
+    dropped = set(dropped_by_rank.get(rank, []))
+    # what the exchange must produce, by plain (unbucketed) all-reduces of the same local gradients: the sink's reference
+    want = {}
+    for k, v in mine.items():
+        w = torch.zeros_like(v.grad) if k in dropped else v.grad.clone()
+        dist.all_reduce(w)
+        want[k] = w / world
     sink.begin_step()
     launched_at = []
     for st in stages:
-        group = {k: (None if (k == dropped and rank == 1) else v.grad) for k, v in mine.items() if k.split(".")[0] == st}
+        group = {k: (None if k in dropped else v.grad) for k, v in mine.items() if k.split(".")[0] == st}
         assert group, st
         sink.deliver(group)
         launched_at.append(len(sink.launch_order))
     sink.finish()
     assert sorted(sink.launch_order) == list(range(len(sink.buckets)))
     assert launched_at[len(stages) // 2] >= 1 and launched_at[len(stages) // 2] < len(sink.buckets)     # collectives start mid-sweep
+    orders = [None] * world
+    dist.all_gather_object(orders, list(sink.launch_order))
+    assert all(o == orders[0] for o in orders), orders                   # every rank issued the same collectives in the same order
+    err = 0.0
+    for k, p in params.items():
+        got = p.grad * sink.grad_scale
+        err = max(err, float((got - want[k]).abs().max() / max(float(want[k].abs().max()), 1e-30)))
     if rank == 0:
-        ref = grads_of(x, tgt, 1.0)
-        err = 0.0
-        for k, p in params.items():
-            got = p.grad * sink.grad_scale
-            want = ref[k].grad if k != dropped else mine[k].grad / world
-            err = max(err, float((got - want).abs().max() / want.abs().max()))
+        nodrop = all(not v for v in dropped_by_rank.values())
+        if nodrop or world == 2:      # also against the single-process gradient of the whole batch where no rank dropped that tensor
+            ref = grads_of(x, tgt, 1.0)
+            alld = set(sum(dropped_by_rank.values(), []))
+            for k, p in params.items():
+                if k not in alld:
+                    err = max(err, float((p.grad * sink.grad_scale - ref[k].grad).abs().max() / ref[k].grad.abs().max()))
         q.put((err, len(sink.buckets), list(sink.launch_order)))
     dist.destroy_process_group()
 
@@ -177,3 +192,22 @@ def test_two_rank_overlapped_allreduce_delivers_in_sweep_order():
         assert p.exitcode == 0
     assert err < 1e-4 and nb > 3
     assert order[0] == 0        # the bucket holding the decoder's last blocks (first to finish in the reverse sweep) goes first
+
+
+def test_three_rank_overlapped_allreduce_uneven_droppath_masks():
+    """Three ranks, one image each, a different set of locally dropped gradients on every rank (uneven DropPath masks): each rank
+    launches the same buckets in the same order (checked with all_gather_object inside the workers) and the exchanged gradients
+    equal plain per-tensor all-reduces of the same local gradients."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    dropped = {0: [], 1: ["encoderlayer_2.blocks.0.mlp.linear1.0.weight", "decoderlayer_0.blocks.0.attn.proj.weight"],
+               2: ["decoderlayer_3.blocks.0.modulator.weight", "encoderlayer_2.blocks.0.mlp.linear1.0.weight", "conv.blocks.0.norm1.bias"]}
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 3, port, q, 3, dropped)) for r in range(3)]
+    for p in procs:
+        p.start()
+    err, nb, order = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-5 and nb > 3 and order[0] == 0

@@ -172,3 +172,35 @@ def test_relative_position_index_check_accepts_only_the_reference_buffer():
     assert train._index_is_standard(idx.clone())
     bad = idx.clone(); bad[3, 5] += 1
     assert not train._index_is_standard(bad)
+
+
+def test_gradient_sink_step_boundaries_and_accumulation():
+    """OverlappedGradientAllReduce state machine: a loop that forgets begin_step() still gets THIS step's gradients
+    (the first deliver after finish starts a new step); begin_step(accumulate=2) adds two backward passes and launches the
+    collectives during the second; one pass too many raises instead of being dropped or double counted."""
+    import pytest
+    import torch
+    from uformer_amd import dist as ud
+    ps = [("a", torch.nn.Parameter(torch.zeros(300))), ("b", torch.nn.Parameter(torch.zeros(500))), ("c", torch.nn.Parameter(torch.zeros(7)))]
+    sink = ud.OverlappedGradientAllReduce(ps, bucket_bytes=2048)
+    assert len(sink.buckets) >= 2
+    g1 = {n: torch.full_like(p, 1.0 + i) for i, (n, p) in enumerate(ps)}
+    g2 = {n: torch.full_like(p, 10.0 + i) for i, (n, p) in enumerate(ps)}
+    sink.deliver(g1); sink.finish()
+    assert all(torch.equal(p.grad, g1[n]) for n, p in ps)
+    sink.deliver(g2); sink.finish()                                   # no begin_step(): must not keep step 1's gradients
+    assert all(torch.equal(p.grad, g2[n]) for n, p in ps)
+    assert sorted(sink.launch_order) == list(range(len(sink.buckets)))
+    sink.deliver({"a": g1["a"]}); sink.finish()                       # parameters without a gradient this step are zero, not stale
+    assert torch.equal(ps[0][1].grad, g1["a"]) and float(ps[1][1].grad.abs().sum()) == 0.0
+    sink.begin_step(accumulate=2)
+    sink.deliver(g1)
+    assert sink.launch_order == []                                    # nothing is reduced before the last pass
+    sink.deliver({"a": g2["a"], "b": None, "c": g2["c"]})              # None in a later pass adds nothing
+    assert sorted(sink.launch_order) == list(range(len(sink.buckets)))
+    sink.finish()
+    assert torch.equal(ps[0][1].grad, g1["a"] + g2["a"]) and torch.equal(ps[1][1].grad, g1["b"]) and torch.equal(ps[2][1].grad, g1["c"] + g2["c"])
+    sink.begin_step()
+    sink.deliver(g1)
+    with pytest.raises(RuntimeError, match="accumulate"):
+        sink.deliver(g2)

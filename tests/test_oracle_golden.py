@@ -374,3 +374,23 @@ def test_tail_ssim_against_second_restatement(golden):
     a, b = t(g["a"]), t(g["b"])
     for i in range(a.shape[0]):
         assert abs(O.ssim(a[i], b[i]) - float(g["ssim"][i])) < 1e-9
+
+
+def test_uformer_T_train_mode_every_parameter(golden):
+    """get_arch('Uformer_T') (head_dim 16, utils/model_utils.py:66-67) in train() mode: the oracle with the recorded DropPath masks vs
+    the reference's forward and autograd gradients (tests/golden/make_golden_r3.py), every parameter through the signed probes."""
+    import fixture_checks as FC
+    g = golden("grad_model_T_128")
+    cfg = spec.arch_config("Uformer_T", img_size=128)
+    assert list(g["heads"]) == list(cfg.num_heads) and all(cfg.embed_dim * m // h == 16 for m, h in zip((1, 2, 4, 8, 16, 16, 8, 4, 2), cfg.num_heads))
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(2, 128, 128, 5321).requires_grad_(True)
+    target = spec.synth_input(2, 128, 128, 5322)
+    masks = t(g["masks"])
+    assert masks.shape == (2 * sum(cfg.depths), 2) and (masks == 0).any()
+    y = O.uformer_forward(x, sd, img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in, drop_scales=masks)
+    loss = O.charbonnier_loss(y, target)
+    loss.backward()
+    grads = {k: v.grad for k, v in sd.items() if v.is_floating_point()}
+    worst = FC.check_grad_T(g, loss.item(), y.detach(), x.grad, grads, rtol=GRAD_RTOL, loss_tol=1e-6, y_tol=5e-5)
+    assert worst["proj"] < GRAD_RTOL

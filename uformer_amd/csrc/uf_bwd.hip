@@ -555,19 +555,23 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restri
 // S, P, dP, dS (softmax row statistics: 4 in-lane tiles + a 16-lane DPP reduction) and keeps its slice of dbias in
 // registers across the windows of the chunk.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T>
+// HD = 32 (every stage of Uformer_S / _B) or 16 (Uformer_T, utils/model_utils.py:66-67: embed_dim 16 with the same head counts).  The
+// token-major tiles keep 32-wide rows for both: with HD = 16 columns [16, 32) are zero-filled once, so the one 32-deep MFMA k-step of
+// S = q k^T and dP = dO v^T contracts over 16 real and 16 zero slots; the d-major tiles and the output tiles simply have HD / 16 of them.
+template <typename T, int HD>
 __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
                                                               const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
                                                               const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
                                                               T* __restrict__ dvt, T* __restrict__ dqkv, float qscale, float* __restrict__ ws_bias, int n_windows,
                                                               int heads, int H, int W, int shift) {
-    constexpr int HD = 32, SZ = sizeof(T), EP = 16 / SZ;
-    constexpr int SD = HD * SZ + 16, ST = 64 * SZ + 16;       // row strides: [token][d] tiles, [d or token][token] tiles
-    constexpr int PPT = 64 * HD / EP / 256;                   // 16-byte pieces per thread and tile (1 bf16, 2 f32)
+    constexpr int SZ = sizeof(T), EP = 16 / SZ, NDT = HD / 16;
+    static_assert(HD == 16 || HD == 32, "head_dim 16 or 32");
+    constexpr int SD = 32 * SZ + 16, ST = 64 * SZ + 16;       // row strides: [token][32 d slots] tiles, [d or token][token] tiles
+    constexpr int NPC = 64 * HD / EP;                         // 16-byte pieces per tile (HD = 32: 256 bf16 / 512 f32; HD = 16: half of that)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;                 char* Ks = Qs + 64 * SD;  char* Vs = Ks + 64 * SD;  char* Gs = Vs + 64 * SD;   // token-major
-    char* QT = Gs + 64 * SD;         char* KT = QT + HD * ST;  char* GT = KT + HD * ST;                              // d-major
-    char* Ps = GT + HD * ST;         char* PT = Ps + 64 * ST;  char* Ds = PT + 64 * ST;  char* DT = Ds + 64 * ST;   // 64 x 64
+    char* QT = Gs + 64 * SD;         char* KT = QT + 32 * ST;  char* GT = KT + 32 * ST;                              // d-major
+    char* Ps = GT + 32 * ST;         char* PT = Ps + 64 * ST;  char* Ds = PT + 64 * ST;  char* DT = Ds + 64 * ST;   // 64 x 64
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int h = blockIdx.x;
@@ -585,12 +589,17 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
         for (int r = 0; r < 4; ++r) br[t][r] = bias_dense[(size_t)h * 4096 + (i0 + 4 * fg + r) * 64 + 16 * t + fr];
     }
 
+    if constexpr (HD == 16) {        // the zero half of the 32-slot rows of the four token-major tiles (never written again)
+        for (int e = tid; e < 4 * 64 * 16; e += 256) {
+            const int tile = e >> 10, row = (e >> 4) & 63, col = 16 + (e & 15);
+            store1(reinterpret_cast<T*>(smem + tile * 64 * SD + row * SD) + col, 0.0f);
+        }
+    }
     for (int bw = w0; bw < w1; ++bw) {
         const size_t base = ((size_t)bw * heads + h) * (64 * HD);
         // ---- stage q, k, dO (token-major + transposed) and v (from v^T, transposed back to token-major)
 #pragma unroll
-        for (int pq = 0; pq < PPT; ++pq) {
-            const int pc = tid + 256 * pq;
+        for (int pc = tid; pc < NPC; pc += 256) {
             {
                 const int i = pc / (HD / EP), pp = pc % (HD / EP);           // token row, piece of the 32 d
                 float fq[EP], fk[EP], fgd[EP];
@@ -675,9 +684,9 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 
         // ---- dq[i][d] = sum_j dS[i][j] k[j][d];  dk[j][d] = sum_i dS[i][j] q[i][d];  dv^T[d][j] = sum_i dO[i][d] P[i][j]
         // wave w: 16-row tile w of dq and dk (both d tiles), 16-column tile w of dv^T (both d tiles); 64-long contraction
-        f32x4 oq[2], ok[2], ov[2];
+        f32x4 oq[NDT], ok[NDT], ov[NDT];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) { oq[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[c] = oq[c]; ov[c] = oq[c]; }
+        for (int c = 0; c < NDT; ++c) { oq[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ok[c] = oq[c]; ov[c] = oq[c]; }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             Frag<T> a_ds, a_dst, b_pt;
@@ -685,7 +694,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
             load_frag(a_dst, reinterpret_cast<const T*>(DT + (i0 + fr) * ST) + ks * 32 + fg * 8);     // rows j, slots i
             load_frag(b_pt, reinterpret_cast<const T*>(PT + (i0 + fr) * ST) + ks * 32 + fg * 8);      // cols j, slots i
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NDT; ++c) {
                 Frag<T> b_kt, b_qt, a_gt;
                 load_frag(b_kt, reinterpret_cast<const T*>(KT + (16 * c + fr) * ST) + ks * 32 + fg * 8);   // cols d, slots j
                 load_frag(b_qt, reinterpret_cast<const T*>(QT + (16 * c + fr) * ST) + ks * 32 + fg * 8);   // cols d, slots i
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
             const int C3 = 3 * heads * HD;
             T* row0 = dqkv + (size_t)bw * 64 * C3 + h * HD;
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < NDT; ++c) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     store1(row0 + (size_t)(i0 + 4 * fg + r) * C3 + 16 * c + fr, oq[c][r] * qscale);
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+            for (int c = 0; c < NDT; ++c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     store1(dq + base + (i0 + 4 * fg + r) * HD + 16 * c + fr, oq[c][r]);
@@ -925,7 +934,7 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
     UF_REQUIRE(q && k && vt && bias_dense && dO && ((dq && dk && dvt) || dqkv) && dbias && ws, UF_ERR_NULL, "uf_window_attention_bwd: null pointer");
     UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: dtype %d", (int)dtype);
     UF_REQUIRE(n_windows > 0 && heads > 0, UF_ERR_SHAPE, "uf_window_attention_bwd: n_windows=%d heads=%d", n_windows, heads);
-    UF_REQUIRE(head_dim == 32, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: head_dim %d (32 only so far)", head_dim);
+    UF_REQUIRE(head_dim == 32 || head_dim == 16, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: head_dim %d (16 or 32)", head_dim);
     UF_REQUIRE(H % 8 == 0 && W % 8 == 0 && H >= 8 && W >= 8 && n_windows % ((H / 8) * (W / 8)) == 0, UF_ERR_SHAPE,
                "uf_window_attention_bwd: H=%d W=%d n_windows=%d", H, W, n_windows);
     UF_REQUIRE(shift == 0 || shift == 4, UF_ERR_UNSUPPORTED, "uf_window_attention_bwd: shift %d (0 or 4)", shift);
@@ -944,12 +953,16 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
     {
         const double pairs = (double)n_windows * heads;
         ScopedTimer tm(name, 2.0 * 5 * 64 * 64 * 32 * pairs, pairs * 64 * 32 * 7.0 * SZ, st);
-        UF_DISPATCH(dtype, TT, {
-            static bool done[64] = {};
-            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<TT>), smem, done, "window_attn_bwd")) return rc;
-            hipLaunchKernelGGL(window_attn_bwd_kernel<TT>, dim3(heads, G), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)vt,
-                               bias_dense, mask, n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
-        });
+#define UF_ATTN_BWD(TT, HDV)                                                                                                                        \
+        {                                                                                                                                              \
+            static bool done[64] = {};                                                                                                                \
+            if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(window_attn_bwd_kernel<TT, HDV>), smem, done, "window_attn_bwd")) return rc;  \
+            hipLaunchKernelGGL((window_attn_bwd_kernel<TT, HDV>), dim3(heads, G), dim3(256), smem, st, (const TT*)q, (const TT*)k, (const TT*)vt,       \
+                               bias_dense, mask, n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows,    \
+                               heads, H, W, shift);                                                                                                   \
+        }
+        UF_DISPATCH(dtype, TT, { if (head_dim == 32) UF_ATTN_BWD(TT, 32) else UF_ATTN_BWD(TT, 16) });
+#undef UF_ATTN_BWD
     }
     int rc = check_launch("window_attn_bwd");
     if (rc) return rc;

@@ -226,11 +226,17 @@ __global__ __launch_bounds__(256) void crop_clamp_kernel(const float* __restrict
 // or f32; layout (N,H,W,3) "hwc" (what cv2 / PIL hand over) or (N,3,H,W).
 template <typename S>
 __global__ __launch_bounds__(256) void crop_aug_kernel(const S* __restrict__ src, float* __restrict__ out, const int* __restrict__ meta /* [B][4]: idx, r0, c0, k */,
-                                                       int B, int H, int W, int ps, int hwc) {
+                                                       int N, int B, int H, int W, int ps, int hwc) {
     const long long n = (long long)B * 3 * ps * ps;
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
         const int j = (int)(t % ps), i = (int)((t / ps) % ps), c = (int)((t / ((long long)ps * ps)) % 3), b = (int)(t / ((long long)3 * ps * ps));
-        const int idx = meta[b * 4], r0 = meta[b * 4 + 1], c0 = meta[b * 4 + 2], k = meta[b * 4 + 3];
+        // device-side metadata is clamped into the frame stack: a bad index or crop origin (user-supplied meta) reads a valid
+        // pixel instead of memory outside the allocation (the host checks N, H, W, ps; the entries themselves live on the device)
+        int idx = meta[b * 4], r0 = meta[b * 4 + 1], c0 = meta[b * 4 + 2];
+        const int k = meta[b * 4 + 3] & 7;
+        idx = idx < 0 ? 0 : (idx >= N ? N - 1 : idx);
+        r0 = r0 < 0 ? 0 : (r0 > H - ps ? H - ps : r0);
+        c0 = c0 < 0 ? 0 : (c0 > W - ps ? W - ps : c0);
         const int ii = (k & 4) ? ps - 1 - i : i;     // flip(-2) is applied last: undo it first
         int sy, sx;
         switch (k & 3) {
@@ -390,8 +396,8 @@ extern "C" int uf_crop_augment(const void* src, int src_is_u8, int src_hwc, floa
     hipStream_t st = (hipStream_t)stream;
     {
         ScopedTimer tm("crop_augment", 0.0, (src_is_u8 ? 5.0 : 8.0) * n, st);
-        if (src_is_u8) hipLaunchKernelGGL(crop_aug_kernel<unsigned char>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const unsigned char*)src, out, meta, B, H, W, ps, src_hwc);
-        else hipLaunchKernelGGL(crop_aug_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const float*)src, out, meta, B, H, W, ps, src_hwc);
+        if (src_is_u8) hipLaunchKernelGGL(crop_aug_kernel<unsigned char>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const unsigned char*)src, out, meta, N, B, H, W, ps, src_hwc);
+        else hipLaunchKernelGGL(crop_aug_kernel<float>, dim3(grid_for(n, 1024)), dim3(256), 0, st, (const float*)src, out, meta, N, B, H, W, ps, src_hwc);
     }
     return check_launch("crop_augment");
 }

@@ -153,7 +153,8 @@ class OverlappedGradientAllReduce:
     * the sum is NOT divided: ``grad_scale`` (1 / world) is handed to ``uformer_amd.optim.AdamW.step`` which folds it into the
       update (``uf_adamw_step``), so the averaged gradient never makes an extra pass through HBM.
     Use: ``sink = OverlappedGradientAllReduce(model); model.grad_sink = sink`` then per step
-    ``sink.begin_step(); loss.backward(); sink.finish(); opt.step(grad_scale=sink.grad_scale)``."""
+    ``sink.begin_step(); loss.backward(); sink.finish(); opt.step(grad_scale=sink.grad_scale)``.  ``begin_step`` may be omitted
+    (the first gradient after ``finish`` starts a new step); ``begin_step(accumulate=k)`` announces k backward passes per step."""
 
     def __init__(self, model_or_named_params, bucket_bytes: int = 25 << 20):
         named = list(model_or_named_params.named_parameters()) if hasattr(model_or_named_params, "named_parameters") else list(model_or_named_params)
@@ -195,47 +196,84 @@ class OverlappedGradientAllReduce:
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
-    def begin_step(self) -> None:
+    def begin_step(self, accumulate: int = 1) -> None:
+        """Start a step of ``accumulate`` backward passes (gradient accumulation): the passes add into the bucket views and the
+        collectives are launched during the LAST one.  Optional for ``accumulate == 1``: the first ``deliver`` after ``finish``
+        begins a new step by itself, so a loop written for the reference (zero_grad / backward / step) cannot silently reuse
+        the previous step's gradients."""
+        if accumulate < 1:
+            raise ValueError("accumulate must be >= 1")
+        self._accumulate = accumulate
+        self._pass = 0
         self._missing = [len(b) for b in self.buckets]
-        self._seen = set()
+        self._seen = set()                                         # names delivered in the current pass
+        self._ever = set()                                         # names delivered in any pass of this step
+        self._launched = set()
         self._works = []
         self.launch_order = []
+        self._finished = False
 
     def _launch(self, b: int) -> None:
+        self._launched.add(b)
         self.launch_order.append(b)
         if self.world > 1:
             self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
 
     def deliver(self, grads) -> None:
         """grads: {parameter name: gradient tensor or None}.  None (a branch DropPath removed on this rank) counts as zeros: the
-        collective must be the same on all ranks."""
+        collective must be the same on all ranks.  A name that arrives again starts the next backward pass of the step: its
+        gradient is ADDED; more passes than ``begin_step(accumulate=...)`` announced is an error (the buckets of the last
+        announced pass are already being reduced)."""
+        if self._finished:
+            self.begin_step()                                      # a new step began without begin_step(): never reuse stale state
         for name, g in grads.items():
-            if name not in self.views or name in self._seen:
+            if name not in self.views:
                 continue
+            if name in self._seen:                                 # second sighting: a new backward pass
+                self._pass += 1
+                if self._pass >= self._accumulate:
+                    raise RuntimeError(f"OverlappedGradientAllReduce: gradient of {name!r} delivered in backward pass {self._pass + 1} of a step announced "
+                                       f"with accumulate={self._accumulate}; call finish() and the optimizer step between backwards, or "
+                                       f"begin_step(accumulate=k) for k backward passes per step")
+                self._seen = set()
+                self._missing = [len(b) for b in self.buckets]
             self._seen.add(name)
             v = self.views[name]
+            first = name not in self._ever
+            self._ever.add(name)
             if g is None:
-                v.zero_()
-            elif g.data_ptr() != v.data_ptr():
-                v.copy_(g.reshape(v.shape))
+                if first:
+                    v.zero_()
+            elif first:
+                if g.data_ptr() != v.data_ptr():
+                    v.copy_(g.reshape(v.shape))
+            else:
+                v.add_(g.reshape(v.shape))
             b = self.bucket_of[name]
             self._missing[b] -= 1
-            if self._missing[b] == 0:
+            if self._missing[b] == 0 and self._pass == self._accumulate - 1:
                 self._launch(b)
+
+    def delivered(self, names) -> bool:
+        """True when every one of ``names`` that lives in a bucket arrived in the current backward pass."""
+        return all((n not in self.views) or (n in self._seen) for n in names)
 
     def finish(self) -> None:
         """Buckets that never completed (parameters without a gradient this step) are zero-filled for the missing entries and
         reduced now; then the compute stream is made to wait for every collective."""
+        if self._finished:
+            return
         for b, idxs in enumerate(self.buckets):
-            if self._missing[b] > 0:
+            if b not in self._launched:
                 for i in idxs:
-                    if self.names[i] not in self._seen:
+                    if self.names[i] not in self._ever:
                         self.views[self.names[i]].zero_()
                 self._missing[b] = 0
                 self._launch(b)
         for w in self._works:
             w.wait()
         self._works = []
+        self._finished = True                                      # the next deliver() starts a fresh step
         for i, p in enumerate(self.params):                        # autograd may have replaced .grad: point it back at the bucket
             if p.grad is None or p.grad.data_ptr() != self.views[self.names[i]].data_ptr():
                 p.grad = self.views[self.names[i]]

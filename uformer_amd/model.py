@@ -11,8 +11,9 @@ methods call the C ABI through ``uformer_amd.ops``.  ``torch.nn`` containers are
 HOLD parameters (so init, ``state_dict`` and optimizers behave as in the reference): no ATen
 math runs on the hot path, and there is no CPU / eager fallback -- CPU inputs raise.
 
-``compute_dtype`` selects the GEMM operand type: ``torch.bfloat16`` (MFMA bf16, f32
-accumulate; the throughput mode) or ``torch.float32`` (exact-f32 MFMA; the 1e-3 parity mode).
+``compute_dtype`` selects the GEMM operand type: ``torch.bfloat16`` (MFMA bf16, f32 accumulate; BASELINE's headline type),
+``torch.float16`` (IEEE half operands, the reference's own AMP type, train/train_denoise.py:180-184: the same MFMA rate and
+within the 1e-3 output tolerance; train it under a loss scale as the reference does) or ``torch.float32`` (exact-f32 MFMA).
 """
 from __future__ import annotations
 
@@ -471,12 +472,19 @@ class Uformer(nn.Module):
         """One workspace per (device, caller stream): two host threads driving the same module on their own streams must
         not scribble over each other's activations."""
         if self._ws is None:
-            self._ws = {}
+            from collections import OrderedDict
+            self._ws = OrderedDict()
         key = (str(device), torch.cuda.current_stream(device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
             ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        self._ws.move_to_end(key)
+        while len(self._ws) > self.MAX_WORKSPACES:       # least recently used first: a caller cycling through PyTorch's stream pool
+            self._ws.popitem(last=False)                 # (32 per priority) must not pin a multi-GB workspace per stream; the block goes
+                                                         # back to the caching allocator's pool of the stream it was allocated (and used) on
         return ws
+
+    MAX_WORKSPACES = 4
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
@@ -489,10 +497,19 @@ class Uformer(nn.Module):
         # (fine-tuning with frozen statistics, input gradients): the fused inference kernels keep no activations and would
         # return a tensor without grad_fn, i.e. silently drop the data term's gradients
         if torch.is_grad_enabled() and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            if mask is not None:
+            if mask is None:
+                return self._forward_train(x)
+            # the autograd path does not take the mask argument (no reference script passes it).  Gradients explicitly asked for
+            # (train() mode, or an input that requires grad): say so.  eval() with grad mode merely left on (``model.eval(); model(x,
+            # mask)`` without torch.no_grad(), the reference's test scripts' habit): run the inference kernels, warn once.
+            if self.training or x.requires_grad:
                 raise NotImplementedError("the mask argument is not supported by the autograd path (no reference script passes it): "
                                           "wrap the call in torch.no_grad() for inference")
-            return self._forward_train(x)
+            if not getattr(self, "_warned_eval_mask", False):
+                import warnings
+                warnings.warn("uformer_amd.Uformer: eval() forward with a mask while grad mode is on runs the inference kernels; the result has no "
+                              "grad_fn (wrap the call in torch.no_grad() to silence this)", stacklevel=2)
+                self._warned_eval_mask = True
         if mask is not None:
             return self._forward_blockwise(x, mask)
         B, _, H, W = x.shape
@@ -521,9 +538,6 @@ class Uformer(nn.Module):
         (train/train_denoise.py:181-184 then calls backward on the loss)."""
         from . import train
         self._check_not_replica()
-        if self.embed_dim % 32 != 0:
-            raise NotImplementedError(f"the backward kernels are built for head_dim 32 (embed_dim a multiple of 32); embed_dim={self.embed_dim} "
-                                      "(Uformer_T, head_dim 16) runs inference only -- use torch.no_grad()")
         sd = self.state_dict(keep_vars=True)
         names, params = list(sd.keys()), list(sd.values())
         sink = getattr(self, "grad_sink", None)

@@ -712,6 +712,10 @@ def lewin_block_bwd(tp, x: Tensor, dy: Tensor, drop_attn: Optional[Tensor], drop
         else:
             rc = lib.uf_lewin_attn_bwd(_byref(tp), _ptr(x), _ptr(dy), _ptr(dx), _ptr(da), _byref(g), B, H, W, C, dt, _ptr(ws), ws.numel(), _stream())
         _lib.check(rc, "uf_lewin_block_bwd" if half == "block" else ("uf_leff_bwd" if half == "leff" else "uf_lewin_attn_bwd"))
+    if half != "block":       # a half writes only its own parameters' gradients: never hand out the other half's uninitialised views
+        mine = {"leff": ("norm2_w", "norm2_b", "w1", "b1", "wdw", "bdw", "w2", "b2"),
+                "attn": ("norm1_w", "norm1_b", "modulator", "rpb_table", "wqkv", "bqkv", "wproj", "bproj")}[half]
+        views = {k: v for k, v in views.items() if k in mine}
     return dx, views
 
 

@@ -310,10 +310,13 @@ class UformerTape:
                 bi = first[s] + i
                 prefix = f"{STAGES[s]}.blocks.{i}."
                 dr = self.drop[2 * bi:2 * bi + 2] if self.drop is not None else None
-                native = self.recompute and C % 32 == 0 and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
+                # the fused kernels (and the block-level C backward built on them) cover head_dim 32; a head_dim-16 block (Uformer_T,
+                # utils/model_utils.py:66-67) takes the op-by-op forward that keeps its intermediates and the op-level backward
+                fusable = self.recompute and C == 32 * cfg.num_heads[s]
+                native = fusable and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
                 pk = self.packs[prefix] = (NativeBlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T) if native else
-                                           BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=self.recompute))
-                if self.recompute:                                              # fused kernels; the block's input is all that is kept
+                                           BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=fusable))
+                if fusable:                                                     # fused kernels; the block's input is all that is kept
                     y = ops.lewin_block_train_fwd(pk.fused, t, B, res[s], res[s], T, None if dr is None else dr[0], None if dr is None else dr[1])
                     self.saved_blocks[s].append(dict(x=t, drop=dr, pk=pk))
                     t = y
@@ -452,7 +455,8 @@ class UformerFunction(torch.autograd.Function):
     def backward(ctx, dy):
         dimg, g = ctx.tape.backward(dy.contiguous(), need_dimg=ctx.img_needs_grad)
         ctx.tape = None                                                           # free the saved activations
-        if ctx.sink is not None:      # the gradients already sit in the sink's buckets (= param.grad) and are being all-reduced
+        if ctx.sink is not None and ctx.sink.delivered([n for n in ctx.names if n in g]):
+            # the gradients already sit in the sink's buckets (= param.grad) and are being all-reduced
             grads = tuple(None for _ in ctx.names)
         else:
             grads = tuple(g.get(n) for n in ctx.names)
