@@ -303,6 +303,7 @@ def main():
     a, b = ud.shard_batch(args.batch * world, rank, world)
     x = spec.synth_input(b - a, args.img, args.img, 1234 + rank).to(dev)
 
+    devices = ud.rank_devices(dev)          # gathered over the process group (RCCL): one row per rank that actually met
     elapsed = timed_steps(model, x, args.steps, args.warmup, ud, dev)
     images = ud.sum_over_ranks(float((b - a) * args.steps), dev)
     # the other operand types: same steps for the 2-byte types, fewer for exact-f32 MFMA (1/16 of the bf16 / f16 rate)
@@ -328,7 +329,9 @@ def main():
             "config": {"workload": f"{args.arch} {args.img}x{args.img} inference, batch {args.batch}/GPU, "
                                    f"synthetic U[0,1) images resident in HBM, synthetic trained-like weights",
                        "global_batch": args.batch * world, "parallelism": f"batch-sharded replicas x{world}, no collective",
-                       "ranks": world, "collective_backend": "RCCL (torch.distributed nccl backend): barrier + max/sum of the timings only"},
+                       "ranks": world, "world_size_reported_by_process_group": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "rank_devices": [{"rank": r[0], "local_rank": r[1], "device_index": r[2], "device_id_hash": r[3]} for r in devices],
+                       "collective_backend": "RCCL (torch.distributed nccl backend): barrier + max/sum of the timings + the rank_devices all-gather only"},
             "model_gflop_per_image": flops_img / 1e9,
             "mfma_frac_whole_model": value * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype],
             "kernel_source_sha": kernel_source_sha(),

@@ -64,6 +64,7 @@ def main():
         opt.step(grad_scale=(sink.grad_scale if sink is not None else 1.0) / ls)
         return loss
 
+    devices = ud.rank_devices("cuda")                                              # all-gathered over RCCL: proof that `world` ranks met
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -78,6 +79,7 @@ def main():
         print(json.dumps({"metric": "training images/sec (fused fwd + recompute bwd + Charbonnier + AdamW kernels)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3,
                           "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss_scale": ls, "loss": float(loss),
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "ranks": world,
+                          "rank_devices": devices,
                           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}))
     if world > 1:
         torch.distributed.destroy_process_group()

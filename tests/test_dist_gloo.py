@@ -160,6 +160,8 @@ def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None):
     sink.finish()
     assert sorted(sink.launch_order) == list(range(len(sink.buckets)))
     assert launched_at[len(stages) // 2] >= 1 and launched_at[len(stages) // 2] < len(sink.buckets)     # collectives start mid-sweep
+    rows = ud.rank_devices("cpu")                                        # what bench.py puts into config.rank_devices: one row per rank that met
+    assert [r[0] for r in rows] == list(range(world)) and all(len(r) == 4 for r in rows)
     orders = [None] * world
     dist.all_gather_object(orders, list(sink.launch_order))
     assert all(o == orders[0] for o in orders), orders                   # every rank issued the same collectives in the same order

@@ -272,3 +272,33 @@ def test_eval_mode_autograd_and_stale_pack_detection():
         w.data = w.data + 0.25                      # new storage, same _version
         y1 = m(x.detach())
     assert (y1 - y0 - 0.25).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("B", [4, 8])
+def test_forward_captured_in_a_hip_graph(B):
+    """uf_uformer_fwd inside a HIP graph (torch.cuda.CUDAGraph; VERDICT r02 "weak" 10).  B = 4 runs on the caller's stream only; B = 8
+    takes the library's default two half-batch parts, i.e. the call forks onto a side stream of its lane pool and joins back
+    before it returns -- a fork/join the capture follows (the side stream enters capture through the fork event and leaves it at
+    the join), so the whole call is one graph either way.  Replays must equal the eager result bit for bit, also after the static
+    input buffer has been refilled."""
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 31)
+    m = build(cfg, sd, torch.float16)
+    xs = [spec.synth_input(B, 128, 128, 40 + i).cuda() for i in range(2)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]                    # eager (also warms the packed weights and the workspace)
+        static_x = xs[0].clone()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):                          # the capture stream's own workspace must exist before capture starts
+            m(static_x)
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            static_y = m(static_x)
+        for i in (0, 1, 0):
+            static_x.copy_(xs[i])
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(static_y, want[i]), (B, i, (static_y - want[i]).abs().max().item())

@@ -204,3 +204,26 @@ def test_gradient_sink_step_boundaries_and_accumulation():
     sink.deliver(g1)
     with pytest.raises(RuntimeError, match="accumulate"):
         sink.deliver(g2)
+
+
+def test_restore_tiled_seams_are_exact_for_a_pointwise_model():
+    """restore_tiled's cutting, zero padding, ramp weights and normalisation (VERDICT r02 "weak" 9): with a model that acts pixel by
+    pixel, tiling must reproduce the full-frame result EXACTLY (to blending round-off) at every pixel, seams and borders
+    included -- a misplaced tile, a wrong ramp or an unnormalised overlap shows up at O(0.1).  (With the real network the tiled
+    result is an approximation by construction: its receptive field spans several hundred pixels.)  Pure torch: runs on the CPU."""
+    import torch
+    from uformer_amd import infer
+    calls = []
+
+    def pointwise(t):
+        calls.append(tuple(t.shape))
+        return 0.5 * t + 0.125 * t * t + 0.1
+
+    g = torch.Generator().manual_seed(3)
+    for (h, w, tile, ov, mb) in ((384, 640, 256, 64, 4), (300, 517, 128, 32, 3), (130, 900, 128, 64, 16)):
+        img = torch.rand(2, 3, h, w, generator=g)
+        calls.clear()
+        got = infer.restore_tiled(pointwise, img, tile=tile, min_overlap=ov, max_batch=mb, clamp=False)
+        assert got.shape == img.shape and all(c[-1] == tile and c[-2] == tile for c in calls)
+        assert (got - pointwise(img)).abs().max().item() < 2e-6, (h, w, tile)
+        assert len(calls) > 1

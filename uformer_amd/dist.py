@@ -54,6 +54,27 @@ def sum_over_ranks(value: float, device="cpu") -> float:
     return float(t.item())
 
 
+def rank_devices(device="cpu"):
+    """Proof that N ranks met: one row per rank -- (rank, local rank, device index, 31-bit hash of the device's identity) -- gathered
+    over the process group's own backend (RCCL for "nccl").  Rank order; a single process returns its own row."""
+    row = [0, 0, -1, 0]
+    rank, local_rank, _ = env_rank_world()
+    row[0], row[1] = rank, local_rank
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        import hashlib
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        pr = torch.cuda.get_device_properties(idx)
+        ident = f"{pr.name}|{getattr(pr, 'uuid', '')}|{getattr(pr, 'pci_bus_id', '')}|{getattr(pr, 'pci_device_id', '')}|{idx}"
+        row[2], row[3] = idx, int.from_bytes(hashlib.sha256(ident.encode()).digest()[:4], "little") & 0x7fffffff
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [row]
+    t = torch.tensor(row, dtype=torch.int64, device=device)
+    rows = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(rows, t)
+    return [[int(v) for v in r.tolist()] for r in rows]
+
+
 def barrier() -> None:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

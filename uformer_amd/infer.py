@@ -56,7 +56,11 @@ def _starts(n: int, tile: int, min_overlap: int) -> List[int]:
 
 @torch.no_grad()
 def restore_tiled(model, img: Tensor, tile: int = 768, min_overlap: int = 128, clamp: bool = True, max_batch: int = 8) -> Tensor:
-    """Overlapped-tile restoration of (B,3,h,w) images: square ``tile`` x ``tile`` windows (a multiple of 128) at evenly spaced
+    """EXPERIMENTAL, beyond the reference (which always pads the whole frame to a square, test/test_sidd.py:106-109): an APPROXIMATION by
+    construction -- the network's receptive field spans several hundred pixels, so a tile does not see what the full frame sees.
+    The mechanics (cutting, padding, ramps, normalisation) are exact: tests/test_host_logic.py checks them to 2e-6 with a pointwise
+    model; against the full-frame result of a real network only a PSNR is reported (tests/test_gpu_tail.py).
+    Overlapped-tile restoration of (B,3,h,w) images: square ``tile`` x ``tile`` windows (a multiple of 128) at evenly spaced
     positions with at least ``min_overlap`` pixels in common, forwarded in batches of ``max_batch`` tiles, blended with a linear
     ramp across each overlap.  An image that fits one tile takes the reference-exact ``restore`` path."""
     if tile % 128:
