@@ -40,7 +40,6 @@ struct AttnBlkParams {
     void* h1;                              // T[B*H*W][4C] or NULL
     const float* drop;                     // training: per-image DropPath scale of this branch (bernoulli(keep)/keep, model.py:986) or NULL
     int n_windows, H, W, shift;
-    int pf;                                // L2 prefetch distance in workgroups (0 = off): phase 0 touches the rows of window bw + pf
     float qscale;
     unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
 };
@@ -195,7 +194,6 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     float* Tab = reinterpret_cast<float*>(smem + 2 * 64 * SA);   // [HEADS][225] compact rel-pos bias
     float* Red = Tab + HEADS * 225;                               // [2][WAVES][64] LN2 partial sums (phase 3)
     float* Bq = Red + 2 * WAVES * 64;                             // [3C] q/k/v bias + [C] proj bias: read from LDS inside the unit walks, not from L2
-    char* Dummy = reinterpret_cast<char*>(Bq + 4 * C);            // 1 KiB landing zone of the prefetch DMA (never read)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,41 +273,13 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
                 gm[i] = *reinterpret_cast<const f32x4*>(p.gamma + (i * LPR + sub) * 4);
                 bt[i] = *reinterpret_cast<const f32x4*>(p.beta + (i * LPR + sub) * 4);
             }
-            // ---- future-window prefetch (p.pf > 0): a window's lifetime starts with a dependent HBM round trip for its 64 rows that only
-            // co-resident workgroups overlap.  Workgroups start in blockIdx order, so the one that takes this CU slot next is about
-            // pf ids ahead (pf ~ workgroups resident chip-wide; a multiple of 8 = same XCD, same L2): its rows are touched now by
-            // LDS-DMA into a landing zone nobody reads -- no registers -- and ITS phase-0 loads hit L2.  VMEM returns in order, so
-            // the DMA is issued only after THIS window's rows have arrived (the asm depends on every row's first reduction) and
-            // flies under the rest of the LayerNorm; the next vector-memory wait is the first weight fragment of phase 1.
-            float row_sum[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float sum = 0.f;
-#pragma unroll
-                for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
-                row_sum[u] = allreduce<RedSum, LPR>(sum);
-            }
-            if (p.pf > 0 && r0 + RPP * U >= 64 && bw + p.pf < p.n_windows) {
-                float dep = 0.f;
-#pragma unroll
-                for (int u = 0; u < U; ++u) dep += row_sum[u];
-                const WinGeom fgeo = window_geom(bw + p.pf, p.H, p.W, p.shift);
-                const unsigned lds_dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Dummy;
-                constexpr int NPW = (C / 4) / WAVES > 0 ? (C / 4) / WAVES : 1;            // 1 KiB DMA instructions per wave: 64 rows x C x 4 B in all
-#pragma unroll
-                for (int k = 0; k < NPW; ++k) {
-                    const int q = (wave * NPW + k) * 64 + lane;                           // 16-byte piece q of the window
-                    const int row = (q / (C / 4)) & 63, c4 = (q % (C / 4)) * 4;
-                    const float* src = p.x + (size_t)window_token(fgeo, row) * p.ld + c4;
-                    unsigned keep;
-                    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "s"(lds_dst), "v"(src), "v"(dep) : "memory");
-                }
-            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = r0 + ((u + rot) & (U - 1)) * RPP + tid / LPR;
-                const float sum = row_sum[u];
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < V4; ++i) sum += (v[u][i][0] + v[u][i][1]) + (v[u][i][2] + v[u][i][3]);
+                sum = allreduce<RedSum, LPR>(sum);
                 const float mean = sum * (1.0f / C);
                 float sq = 0.f;
 #pragma unroll
@@ -659,7 +629,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 
 template <typename T, int C, int NT>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
-    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4 + 1024;   // + the prefetch landing zone
+    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT>;
     static bool lds_done[64] = {};
@@ -705,8 +675,6 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = debug_get_tbuf();
-    static const int pf_env = getenv("UF_PF_ATTN") ? atoi(getenv("UF_PF_ATTN")) : 0;      // workgroups; rounded to a multiple of 8 (same XCD)
-    p.pf = pf_env > 0 ? (pf_env + 7) / 8 * 8 : 0;
 
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
 #define UF_AB_HALF(TT)                                                                                                              \

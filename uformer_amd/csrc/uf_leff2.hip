@@ -25,7 +25,6 @@ struct Leff2Params {
     float* x; int ld;               // residual stream rows, in place
     const float* drop;              // training: per-image DropPath scale of the branch (model.py:987) or NULL
     int B, H, W;
-    int pf;                     // L2 prefetch distance in workgroups (0 = off): see "future-tile prefetch" in the kernel
     unsigned long long* tbuf;   // optional per-role cycle totals of sampled blocks (uf_debug_set_tbuf)
 };
 
@@ -172,50 +171,7 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
 #pragma unroll
         for (int it = 0; it < NBUF - 1; ++it)
             if (it < NIT) issue(it);
-        // ---- future-tile prefetch (p.pf > 0).  A tile's lifetime is a chain of dependent HBM round trips (the first interval's halo
-        // tile before anything can start, the residual rows in the epilogue) that only co-resident workgroups overlap.  Workgroups
-        // start in blockIdx order, so the one that will take this CU slot next is about `pf` ids ahead (pf ~ workgroups resident
-        // chip-wide, a multiple of 8: same XCD, same L2): its first intervals' halo pieces and its residual rows are touched NOW --
-        // LDS-DMA into the landing zone, no registers, nobody reads them -- so that ITS prologue and epilogue loads hit L2.
-        // Issued after this workgroup's own prologue loads (VMEM returns in order: they must not queue behind HBM misses) and
-        // left in flight across B0 by a counted wait.
-        constexpr int NPFI = NIT < 2 ? NIT : 2;                                  // intervals of the future tile to touch
-        constexpr int NXP = 64 * C * 4 / 1024;                                   // 1 KiB pieces of its 64 residual rows
-        constexpr int NPFW = (NPFI * NHI + NXP + NP - 1) / NP;                    // prefetch DMA slots per producer wave (uniform)
-        const bool do_pf = p.pf > 0 && (int)blockIdx.x + p.pf < (int)gridDim.x;
-        if (do_pf) {
-            const int ft = xcd_tile(blockIdx.x + p.pf, gridDim.x);
-            const int fb = ft / (tiles_x * tiles_y), ftr = ft - fb * (tiles_x * tiles_y);
-            const int fy0 = (ftr / tiles_x) * TH, fx0 = (ftr % tiles_x) * TW;
-            const char* fimg = reinterpret_cast<const char*>(p.h1) + (size_t)fb * p.H * p.W * HID * SZ;
-            const unsigned long long fa = (unsigned long long)(uintptr_t)fimg;
-            const u32x4 frs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(fa >> 32)) & 0xffffu,
-                               (unsigned)__builtin_amdgcn_readfirstlane(p.H * p.W * HID * SZ), 0x00020000u};
-#pragma unroll
-            for (int s = 0; s < NPFW; ++s) {
-                const int idx = wave + s * NP;                                   // wave-uniform
-                if (idx < NPFI * NHI) {
-                    const int it = idx / NHI, hidx = idx - it * NHI;
-                    const int g = hidx / NHG, q = (hidx - g * NHG) * 64 + lane;
-                    const int hp = q / CPP, part = q - hp * CPP;
-                    const int hy = hp / HW_, hx = hp - hy * HW_;
-                    const int iy = fy0 + hy - 1, ix = fx0 + hx - 1;
-                    unsigned vo = 0xffffff00u;
-                    if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) vo = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + part * 16);
-                    dma_buffer_to_lds(frs, vo, (unsigned)(it * KC * SZ), lds_dummy);
-                } else if (idx < NPFI * NHI + NXP) {
-                    const int q = (idx - NPFI * NHI) * 64 + lane;                // 16-byte piece q of the tile's residual rows
-                    const int pm = q / (C / 4), c4 = (q - pm * (C / 4)) * 4;
-                    const float* src = p.x + ((size_t)(fb * p.H + fy0 + (pm >> 3)) * p.W + fx0 + (pm & 7)) * p.ld + c4;
-                    dma_global_to_lds(src, lds_dummy);
-                } else {
-                    dma_buffer_to_lds(rsrc, 0xffffff00u, 0u, lds_dummy);
-                }
-            }
-            wait_dma<NPFW>();
-        } else {
-            wait_dma<0>();
-        }
+        wait_dma<0>();
         lds_barrier();                                                          // B0: intervals 0 .. NBUF-2 staged
         unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
 #pragma unroll 1
@@ -432,8 +388,6 @@ int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* 
     Leff2Params p{};
     p.tbuf = debug_get_tbuf();
     p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W; p.drop = drop;
-    static const int pf_env = getenv("UF_PF_LEFF2") ? atoi(getenv("UF_PF_LEFF2")) : 0;     // workgroups; rounded to a multiple of 8 (same XCD)
-    p.pf = pf_env > 0 ? (pf_env + 7) / 8 * 8 : 0;
     if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
     if (dtype == UF_F16) return launch_t<f16>(p, C, st);
     if (dtype == UF_F32) return launch_t<float>(p, C, st);
