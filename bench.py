@@ -370,19 +370,24 @@ def main():
                                "frac": ach / HBM_PEAK_GBS, "traffic": None}
         # HBM bytes per launch of that kernel from the PMC passes of scripts/official_run.sh -- only if they were collected on
         # exactly these kernel sources (stamp); a number from an older build would silently go stale, so it is dropped instead
-        try:
-            with open(os.path.join(REPO, "profiles", "r02_pmc_traffic.json")) as f:
-                tj = json.load(f)
-            if tj.get("kernel_source_sha") == out["kernel_source_sha"]:
-                tr = tj["kernels"].get(name)
-                if tr:
-                    out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = ("HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (separate --pmc passes of this workload, same "
-                                                       f"kernel sources: profiles/r02_pmc_traffic.json); algorithmic bytes per launch {dom['bytes'] / dom['launches']:.4g}")
-            else:
-                out["roofline"]["traffic_note"] = "null: profiles/r02_pmc_traffic.json was measured on other kernel sources (stamp mismatch)"
-        except (OSError, ValueError, KeyError):
-            out["roofline"]["traffic_note"] = "null: no PMC passes of this build (scripts/official_run.sh collects them)"
+        tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True)       # newest round first
+        note = "null: no PMC passes of this build (scripts/official_run_r03.sh collects them)"
+        for tf in tfiles:
+            try:
+                with open(tf) as f:
+                    tj = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if tj.get("kernel_source_sha") != out["kernel_source_sha"]:
+                note = f"null: {os.path.basename(tf)} was measured on other kernel sources (stamp mismatch)"
+                continue
+            tr = tj.get("kernels", {}).get(name)
+            if tr:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                note = ("HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (separate --pmc passes of this workload, same "
+                        f"kernel sources: profiles/{os.path.basename(tf)}); algorithmic bytes per launch {dom['bytes'] / dom['launches']:.4g}")
+            break
+        out["roofline"]["traffic_note"] = note
         out["roofline"]["flop_per_byte"] = dom["flops"] / max(dom["bytes"], 1.0)
         out["roofline"]["achieved_tflops"] = dom["flops"] / sec / 1e12
         out["roofline"].update({"kernel": name, "launches_per_step": dom["launches"] // 3,

@@ -51,7 +51,7 @@ def first(*names):
         if os.path.exists(f"{src}/{n}"):
             return f"{src}/{n}"
     raise SystemExit(f"none of {names} under {src}")
-fetch, write = load(first("pmcC_pmc.csv", "r02_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r02_final_pmcD.csv"), "WRITE_SIZE")
+fetch, write = load(first("pmcC_pmc.csv", "r03_final_pmcC.csv", "r02_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r03_final_pmcD.csv", "r02_final_pmcD.csv"), "WRITE_SIZE")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before it quotes these numbers)
 out = {}
@@ -59,7 +59,7 @@ for s in sorted(fetch):
     f, n = fetch[s]
     w = write.get(s, (0.0, 0))[0]
     out[s] = {"fetch_bytes_per_launch": 2.0 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2.0 * f + w, "dispatches_profiled": n}
-json.dump({"kernel_source_sha": bench.kernel_source_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-f32-mode (UF_STREAMS=1); "
+json.dump({"kernel_source_sha": bench.kernel_source_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-modes --no-train-mode (UF_STREAMS=1); "
                      "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; average over the launches of a symbol",
            "kernels": out}, open(dst, "w"), indent=1)
 for s, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

@@ -560,3 +560,28 @@ def test_uformer_T_head_dim16_trains_vs_reference_autograd(golden, dtype):
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/parity_grad_T_{TAG[dtype]}.json", "w") as f:
         json.dump(worst, f)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_standalone_block_module_is_differentiable(golden, dtype):
+    """LeWinTransformerBlock as an ordinary differentiable nn.Module (the reference's is one, model.py:908-989; VERDICT r02 "missing"
+    6): y = blk(x); y.backward(gy) in train() mode against the reference's autograd on the same block (tests/golden/grad_lewin_block.npz:
+    shifted windows, 2 heads, modulator)."""
+    import numpy as np
+    from uformer_amd import model
+    gd = golden("grad_lewin_block")
+    t = lambda a: torch.from_numpy(np.asarray(a))                           # noqa: E731
+    C, heads = 64, int(gd["heads"])
+    blk = model.LeWinTransformerBlock(C, (16, 16), heads, win_size=8, shift_size=4, token_mlp="leff", modulator=True)
+    blk.load_state_dict({k[2:]: t(v) for k, v in gd.items() if k.startswith("p.")}, strict=True)
+    blk = blk.cuda().train()
+    x = t(gd["x"]).cuda().requires_grad_(True)
+    y = blk(x, compute_dtype=dtype)
+    assert y.grad_fn is not None
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    y.backward(t(gd["gy"]).cuda() * ls)
+    tol = pick(dtype, 1e-3, 6e-2)
+    assert rel(y.detach(), t(gd["y"])) < pick(dtype, 1e-5, 1e-2)
+    assert rel(x.grad / ls, t(gd["dx"])) < tol
+    for n, p_ in blk.named_parameters():
+        assert rel(p_.grad / ls, t(gd["g." + n])) < tol, n

@@ -293,9 +293,23 @@ class LeWinTransformerBlock(nn.Module):
         return torch.where(am != 0, torch.full_like(am, -100.0), torch.zeros_like(am)).contiguous()
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, compute_dtype=torch.float32) -> Tensor:
-        """(B, L, C) -> (B, L, C); eval semantics (DropPath is identity)."""
+        """(B, L, C) -> (B, L, C).  With grad mode on and something to differentiate (train() mode, an input or a parameter that
+        requires grad) the block is an autograd node like the reference's (model.py:908-989): op-by-op forward that keeps its
+        intermediates + the op-level backward (uformer_amd.train.LeWinBlockFunction), timm's DropPath per sample in train() mode.
+        Otherwise: the fused inference kernels (DropPath is the identity)."""
+        if torch.is_grad_enabled() and mask is None and (self.training or x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from . import train
+            if not x.is_cuda:
+                raise UformerHipError("LeWinTransformerBlock runs on the GPU only; there is no CPU path")
+            named = [(n, t) for n, t in self.state_dict(keep_vars=True).items()]
+            drop = None
+            if self.training and self.drop_path_rate > 0.0:
+                drop = getattr(self, "_drop_scales_override", None)
+                if drop is None:
+                    drop = train.sample_drop_scales([self.drop_path_rate], x.shape[0], x.device)
+            return train.LeWinBlockFunction.apply(x, [n for n, _ in named], self.num_heads, self.shift_size, compute_dtype, drop, *[t for _, t in named])
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("block-level autograd is not wired: train through Uformer.forward (uformer_amd/train.py) or use eval()/no_grad")
+            raise NotImplementedError("the mask argument is not supported by the block's autograd path (no reference script passes it)")
         B, L, Cc = x.shape
         H = W = int(math.sqrt(L))
         if not x.is_cuda:

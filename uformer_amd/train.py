@@ -463,6 +463,26 @@ class UformerFunction(torch.autograd.Function):
         return (dimg if ctx.img_needs_grad else None, None, None, None, None) + grads
 
 
+class LeWinBlockFunction(torch.autograd.Function):
+    """torch.autograd entry of ONE LeWin block (the reference's LeWinTransformerBlock is an ordinary differentiable module,
+    model.py:908-989): ``y = LeWinBlockFunction.apply(x, prefix_free_names, heads, shift, dtype, drop, *params)`` with x (B, L, C).
+    Forward = the op-by-op forward that keeps its intermediates, backward = the op-level backward (lewin_block_forward /
+    lewin_block_backward above); ``drop``: None or (2, B) DropPath scales of the two residual branches."""
+
+    @staticmethod
+    def forward(ctx, x, names, heads, shift, dtype, drop, *params):
+        p = {n: t.detach() for n, t in zip(names, params)}
+        y, sv = lewin_block_forward(x.detach().float().contiguous(), p, "", heads, shift, dtype, drop)
+        ctx.sv, ctx.names, ctx.x_needs_grad, ctx.x_dtype = sv, names, x.requires_grad, x.dtype
+        return y.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dx, g = lewin_block_backward(ctx.sv, dy.float().contiguous())
+        ctx.sv = None
+        return (dx.to(ctx.x_dtype) if ctx.x_needs_grad else None, None, None, None, None, None) + tuple(g.get(n) for n in ctx.names)
+
+
 class NamesWithSink(list):
     """parameter names + the gradient sink (uformer_amd.dist.OverlappedGradientAllReduce) the tape delivers to during backward"""
     sink = None
