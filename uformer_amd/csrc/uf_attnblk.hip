@@ -79,6 +79,15 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef UF_FC1_RING
 #define UF_FC1_RING 5
 #endif
+// UF_HOIST: the first weight fragments of a GEMM phase are requested BEFORE the phase in front of it (q/k/v weights before the LayerNorm
+// of phase 0, the next unit's right behind the current unit's last MFMA, proj weights + residual rows in front of the barrier that ends
+// phase 1, fc1 weights in front of LN2): at C <= 128 a phase is 2-4 k-steps long, so the L2 round trip of its first fragments was as
+// long as the phase itself and nothing hid it.  Bit-identical results (same MFMAs on the same operands).  Bit mask of widths it is on for:
+// 1: C <= 128, 2: C = 256, 4: C = 512 (register budgets differ).
+#ifndef UF_HOIST
+#define UF_HOIST 1
+#endif
+template <int C> constexpr bool hoist_on() { return (C <= 128 && (UF_HOIST & 1)) || (C == 256 && (UF_HOIST & 2)) || (C == 512 && (UF_HOIST & 4)); }
 
 template <typename T> struct FragFromAcc {   // primary: the 2-byte operand types
     static __device__ __forceinline__ void make(Frag<T>& f, f32x4 a, f32x4 b) {
@@ -102,31 +111,38 @@ template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // bala
 // LDS: the barrier-free 64 x 64 unit walk of ln_gemm (uf_lngemm.hip) -- fragment-major weights streamed L2 -> registers
 // through a 3-deep ring pinned with sched_barrier, first k-steps of the next unit issued before the epilogue, and the
 // permlane-widened direct 16-byte stores.  2-byte operand types only.
+// Fc1Walk::first(): the weight fragments of the wave's first unit (callable before the operand tile exists: UF_HOIST);
+// Fc1Walk::run(): the walk.
 template <typename T, int C, int WAVES>
-__device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, const float* b1, T* h1, const WinGeom& geo,
-                                          int wave, int lane) {
-    // RING k-steps of weight fragments in flight: one k-step is only 16 MFMAs (256 cycles) per wave, an L2 round trip under
-    // load is 1-2 K cycles -- with 3 slots the walk stalled on every k-step (stamps: 3-4x the MFMA time); 16 registers a slot
-    constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / 64;
-    static_assert(SZ == 2, "direct-store epilogue packs pairs of a 2-byte type");
-    const int fr = lane & 15, fg = lane >> 4;
+struct Fc1Walk {
+    static constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / 64;
     const T* wrow[4];
     Frag<T> wf[RING][4];
-    auto wload = [&](int ks, int slot) {
+    const T* W1;
+    int lane;
+    __device__ __forceinline__ void wload(int ks, int slot) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
-    };
-    auto unit_prefetch = [&](int u) {
+    }
+    __device__ __forceinline__ void unit_prefetch(int u) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) wrow[i] = W1 + ((size_t)(u * 4 + i) * KS * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s)
             if (s < KS) wload(s, s);
-    };
+    }
+    __device__ __forceinline__ void first(const T* W1_, int wave, int lane_) {
+        W1 = W1_; lane = lane_;
+        if (wave < UNITS) unit_prefetch(wave);
+    }
+    __device__ __forceinline__ void run(const char* Xn, int SA, const float* b1, T* h1, const WinGeom& geo, int wave) {
+    // RING k-steps of weight fragments in flight: one k-step is only 16 MFMAs (256 cycles) per wave, an L2 round trip under
+    // load is 1-2 K cycles -- with 3 slots the walk stalled on every k-step (stamps: 3-4x the MFMA time); 16 registers a slot
+    static_assert(SZ == 2, "direct-store epilogue packs pairs of a 2-byte type");
+    const int fr = lane & 15, fg = lane >> 4;
     size_t rowoff[4];   // h1 row of this lane's token in each 16-row tile (window_reverse + roll back, as the residual rows)
 #pragma unroll
     for (int j = 0; j < 4; ++j) rowoff[j] = (size_t)window_token(geo, j * 16 + fr) * N4;
-    if (wave < UNITS) unit_prefetch(wave);
     if (WAVES == 8 && UF_FC1_OFFSET > 0 && wave >= 4) __builtin_amdgcn_s_sleep(UF_FC1_OFFSET * (C / 256) > 127 ? 127 : UF_FC1_OFFSET * (C / 256));   // as in phase 1
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
@@ -176,7 +192,13 @@ __device__ __forceinline__ void fc1_units(const char* Xn, int SA, const T* W1, c
             }
         }
     }
-}
+    }
+};
+
+struct NoWalk {   // f32 operands: phase 3 does not exist
+    template <typename... A> __device__ __forceinline__ void first(A...) {}
+    template <typename... A> __device__ __forceinline__ void run(A...) {}
+};
 
 template <typename T, int C, int NT>
 __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2)) void attn_block_kernel(const AttnBlkParams p) {
@@ -221,6 +243,27 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         i = i < NTABV ? i : NTABV - 1;
         const float* src = i < HEADS * 225 ? p.rpb_tab + i : (i < HEADS * 225 + 3 * C ? p.bqkv + (i - HEADS * 225) : p.bp + (i - HEADS * 225 - 3 * C));
         tabv[k] = *src;
+    }
+    // q/k/v weight ring of phase 1 (k-steps of L2 -> register loads in flight) and the first unit's prologue, see UF_HOIST
+    constexpr bool HOIST = hoist_on<C>() && SZ == 2;      // (the f32 parity variants have no registers to spare)
+    constexpr int WR = (SZ == 2 && C >= 256) ? UF_QKV_RING : ((SZ == 2 && C >= 128) ? 3 : 2);
+    const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
+    const T* wrow[6];
+    Frag<T> wf[WR][6];
+    auto wload = [&](int ks, int slot) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+    };
+    auto unit_weights = [&](int u) {   // 16-row weight tiles of the unit's head in the fragment-major Wqkv (q tiles h*2+i, k tiles C/16+.., v tiles 2C/16+..) + ring prologue
+        const int h = u / (4 / QT);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int pf = 0; pf < WR - 1; ++pf)
+            if (pf < KS) wload(pf, pf);
+    };
+    if constexpr (HOIST) {
+        if (wave < UNITS) unit_weights(wave);
     }
     // ---------------- phase 0: LN1 (+gather, +modulator) -> Xn --------------------------------------
     {
@@ -316,7 +359,6 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     const int wi = bw % nW;
     const bool last_r = p.shift > 0 && (wi / nWc) == (p.H >> 3) - 1;
     const bool last_c = p.shift > 0 && (wi % nWc) == nWc - 1;
-    const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
 
     // ---------------- phase 1: per-unit QKV projection + attention, all in registers -------------------
     // 8-wave workgroups put TWO of their waves on every SIMD, and the barriers keep them in lockstep: both fight for the matrix
@@ -334,19 +376,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 #pragma unroll
             for (int j = 0; j < 4; ++j) { ak[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; av[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         }
-        // 16-row weight tiles of this head in the fragment-major Wqkv: q tiles h*2+i, k tiles C/16+.., v tiles 2C/16+..
-        const T* wrow[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;   // fragment-major tiles
-        // weight fragments come from L2 (>= 500 cycles): ring of WR k-steps in flight where registers allow; the
-        // activation fragments come from LDS, one step ahead is enough
-        constexpr int WR = (SZ == 2 && C >= 256) ? UF_QKV_RING : ((SZ == 2 && C >= 128) ? 3 : 2);
-        Frag<T> wf[WR][6], af[2][4];
+        // weight fragments come from L2 (>= 500 cycles): ring of WR k-steps in flight where registers allow (declared in front of
+        // phase 0); the activation fragments come from LDS, one step ahead is enough
+        Frag<T> af[2][4];
         Frag<T> afq[2][QT < 4 ? QT : 1];   // query-tile fragments when q0 is a runtime value (static register indexing only)
-        auto wload = [&](int ks, int slot) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
-        };
+        if constexpr (!HOIST) unit_weights(u);
         auto aload = [&](int ks, int slot) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
@@ -356,9 +390,6 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
                     load_frag(afq[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
             }
         };
-#pragma unroll
-        for (int pf = 0; pf < WR - 1; ++pf)
-            if (pf < KS) wload(pf, pf);
         aload(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -383,6 +414,9 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
             __builtin_amdgcn_sched_barrier(0);
         }
         if (u == wave) stamp(3);
+        if constexpr (HOIST) {      // the next unit's first weight fragments fly under this unit's attention (the ring is free)
+            if (u + WAVES < UNITS) unit_weights(u + WAVES);
+        }
         // bias (+ scale on q, model.py:497), then the accumulators ARE the attention operands
         Frag<T> qf[QT], kf[4], vtf[2][2];
         {
@@ -499,9 +533,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         if (u == wave) stamp(4);
     }
     stamp(5);
-    lds_barrier();
-    stamp(6);
-
+    std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
     // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------
     {
         constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;
@@ -524,10 +556,6 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 #pragma unroll
             for (int j = 0; j < TMW; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Os + ((wm * TMW + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
         };
-#pragma unroll
-        for (int pf = 0; pf < PR - 1; ++pf)
-            if (pf < KS) wload(pf, pf);
-        aload(0, 0);
         // the rows this wave updates: addresses now, and (2-byte operand types: registers allow it) the residual values and
         // the bias requested BEFORE the k-loop, so that their round trip (L2: the rows were read in phase 0) hides under it
         float* xrow[TMW];
@@ -535,14 +563,24 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         for (int j = 0; j < TMW; ++j) xrow[j] = p.x + (size_t)window_token(geo, (wm * TMW + j) * 16 + fr) * p.ld;
         constexpr bool PRE = SZ == 2;
         f32x4 res[PRE ? TNW : 1][PRE ? TMW : 1];
-        if constexpr (PRE) {
+        auto proj_requests = [&]() {       // what does not depend on the O tile: weight prologue, residual rows
 #pragma unroll
-            for (int i = 0; i < TNW; ++i) {
-                const int n = (wn * TNW + i) * 16 + fg * 4;
+            for (int pf = 0; pf < PR - 1; ++pf)
+                if (pf < KS) wload(pf, pf);
+            if constexpr (PRE) {
 #pragma unroll
-                for (int j = 0; j < TMW; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(xrow[j] + n);
+                for (int i = 0; i < TNW; ++i) {
+                    const int n = (wn * TNW + i) * 16 + fg * 4;
+#pragma unroll
+                    for (int j = 0; j < TMW; ++j) res[i][j] = *reinterpret_cast<const f32x4*>(xrow[j] + n);
+                }
             }
-        }
+        };
+        if constexpr (HOIST) proj_requests();      // in flight across the barrier (UF_HOIST): waves that finish phase 1 early wait there anyway
+        lds_barrier();
+        stamp(6);
+        if constexpr (!HOIST) proj_requests();
+        aload(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + PR - 1 < KS) wload(ks + PR - 1, (ks + PR - 1) % PR);
@@ -572,6 +610,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         }
         if constexpr (SZ == 2) {
             if (p.h1) {
+                if constexpr (HOIST) fc1w.first(reinterpret_cast<const T*>(p.W1), wave, lane);
                 // ---- LN2 of the new rows (model.py:987): two-pass mean / variance; a token's C channels are spread over
                 // the 4 lane groups of a wave (xor 16, 32) and the WN waves of its row group (LDS).  All sums are balanced
                 // binary trees over the 16-channel tiles, so the result does not depend on how many waves share a row
@@ -620,7 +659,8 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         if (p.h1) {
             lds_barrier();
             stamp(11);
-            fc1_units<T, C, WAVES>(Xn, SA, reinterpret_cast<const T*>(p.W1), p.b1, reinterpret_cast<T*>(p.h1), geo, wave, lane);
+            if constexpr (!HOIST) fc1w.first(reinterpret_cast<const T*>(p.W1), wave, lane);
+            fc1w.run(Xn, SA, p.b1, reinterpret_cast<T*>(p.h1), geo, wave);
             stamp(12);
         }
     }
