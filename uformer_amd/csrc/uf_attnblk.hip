@@ -62,7 +62,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define UF_PRIO_UP() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define UF_PRIO_DN() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef UF_ABL
-#define UF_ABL 0   // phase-0 ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads); 0 in every shipped build
+#define UF_ABL 0   // ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads, 4: no h1 stores, 5: no row stores in phase 2); 0 in every shipped build
 #endif
 #ifndef UF_LN_ROTATE
 #define UF_LN_ROTATE 0
@@ -82,10 +82,12 @@ constexpr float LOG2E = 1.4426950408889634f;
 // UF_HOIST: the first weight fragments of a GEMM phase are requested BEFORE the phase in front of it (q/k/v weights before the LayerNorm
 // of phase 0, the next unit's right behind the current unit's last MFMA, proj weights + residual rows in front of the barrier that ends
 // phase 1, fc1 weights in front of LN2): at C <= 128 a phase is 2-4 k-steps long, so the L2 round trip of its first fragments was as
-// long as the phase itself and nothing hid it.  Bit-identical results (same MFMAs on the same operands).  Bit mask of widths it is on for:
-// 1: C <= 128, 2: C = 256, 4: C = 512 (register budgets differ).
+// long as the phase itself and nothing hid it; fc1 weights are also requested in front of the row stores of phase 2 (vector memory
+// returns in order and the counter covers stores: fragments requested behind the store burst wait for its last ack).  Bit-identical
+// results (same MFMAs on the same operands).  Bit mask of widths it is on for: 1: C <= 128, 2: C = 256, 4: C = 512.  Measured
+// (profiles/r03_hoist2_ab.txt, four interleaved rounds): attn_block 3.98 -> 3.88 ms per step with every width on (7), the default.
 #ifndef UF_HOIST
-#define UF_HOIST 1
+#define UF_HOIST 7
 #endif
 template <int C> constexpr bool hoist_on() { return (C <= 128 && (UF_HOIST & 1)) || (C == 256 && (UF_HOIST & 2)) || (C == 512 && (UF_HOIST & 4)); }
 
@@ -188,7 +190,8 @@ struct Fc1Walk {
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
                 const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
-                *reinterpret_cast<u32x4*>(h1 + rowoff[j] + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if (UF_ABL == 4) asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]), "v"(h1 + rowoff[j] + n));   // ablation: no h1 stores
+                else *reinterpret_cast<u32x4*>(h1 + rowoff[j] + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
     }
@@ -595,6 +598,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp(7);
+        if constexpr (SZ == 2 && HOIST) {
+            // phase 3's first weight fragments are requested BEFORE this phase's row stores: vector memory returns in order and the
+            // counter covers stores too, so fragments requested behind the 64 x C x 4-byte store burst would wait for its last ack
+            if (p.h1) fc1w.first(reinterpret_cast<const T*>(p.W1), wave, lane);
+        }
         const float dscale = p.drop ? p.drop[geo.img] : 1.0f;   // DropPath: x + scale_b * branch (timm, train mode only)
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
@@ -605,12 +613,12 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
                 const f32x4 b = *reinterpret_cast<const f32x4*>(Bq + 3 * C + n);
                 if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b) * dscale;   // the block's new rows stay in registers
                 else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b) * dscale;
-                *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
+                if (UF_ABL == 5) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]), "v"(xr + n));   // ablation: no row stores
+                else *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
             }
         }
         if constexpr (SZ == 2) {
             if (p.h1) {
-                if constexpr (HOIST) fc1w.first(reinterpret_cast<const T*>(p.W1), wave, lane);
                 // ---- LN2 of the new rows (model.py:987): two-pass mean / variance; a token's C channels are spread over
                 // the 4 lane groups of a wave (xor 16, 32) and the WN waves of its row group (LDS).  All sums are balanced
                 // binary trees over the 16-channel tiles, so the result does not depend on how many waves share a row
