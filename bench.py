@@ -278,6 +278,7 @@ def main():
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-f32 mode")
     ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
     ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
+    ap.add_argument("--train-mode-multi", action="store_true", help="run modes.train under N > 1 too (gradient all-reduce over RCCL)")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-warmup", type=int, default=1)
@@ -315,7 +316,9 @@ def main():
             e2 = timed_steps(m2, x, steps2, 2, ud, dev)
             others[other] = (m2, e2, steps2, ud.sum_over_ranks(float((b - a) * steps2), dev))
     train_entry = None
-    if not args.no_train_mode and args.arch == "Uformer_B":
+    # modes.train rides along at N = 1 (like cpu_baseline); under N > 1 it would add the RCCL gradient exchange to a run whose
+    # subject is the inference metric -- scripts/scale.sh / scripts/train_bench.py measure that one on its own (--train-mode-multi forces it here)
+    if not args.no_train_mode and args.arch == "Uformer_B" and (world == 1 or args.train_mode_multi):
         train_entry = train_mode(args, cfg, sd, dev, ud, args.train_dtype)
 
     out = None
