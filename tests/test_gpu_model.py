@@ -302,3 +302,25 @@ def test_forward_captured_in_a_hip_graph(B):
             g.replay()
             torch.cuda.synchronize()
             assert torch.equal(static_y, want[i]), (B, i, (static_y - want[i]).abs().max().item())
+
+
+def test_eval_mode_with_mask_and_grad_mode_on_falls_back_with_one_warning():
+    """``model.eval(); model(x, mask)`` without torch.no_grad() (grad mode on by default, parameters require grad) used to be
+    pushed onto the autograd path, which does not take a mask, and raised.  It now runs the inference kernels (the module-by-module mask
+    path), warns once, and equals the no_grad result; an input that requires grad still raises -- gradients were asked for explicitly."""
+    import warnings
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 11)
+    m = build(cfg, sd, torch.float32)
+    x = spec.synth_input(1, 128, 128, 12).cuda()
+    mask = (torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(5)) > 0.3).float().cuda()
+    with torch.no_grad():
+        want = m(x, mask)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        y1 = m(x, mask)
+        y2 = m(x, mask)
+    assert y1.grad_fn is None and torch.equal(y1, want) and torch.equal(y2, want)
+    assert sum("inference kernels" in str(i.message) for i in w) == 1
+    with pytest.raises(NotImplementedError, match="mask"):
+        m(x.clone().requires_grad_(True), mask)
