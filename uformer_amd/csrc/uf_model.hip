@@ -60,7 +60,11 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     // window_reverse and the residual never leave the CU                       (model.py:951-986)
     static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
     static const bool no_fc1 = getenv("UF_NO_FC1_FUSION") != nullptr;
-    if (!no_fuse && attn_block_supported(p, user_mask, dtype, C, heads)) {
+    // UF_UNFUSE_BELOW=n (experiment): stages with fewer than n windows take the 3-kernel path, whose GEMMs tile over the whole chip where
+    // the fused kernel has one workgroup per window (64 windows at the bottleneck of a batch of 16)
+    static const int unfuse_below = getenv("UF_UNFUSE_BELOW") ? atoi(getenv("UF_UNFUSE_BELOW")) : 0;
+    const bool small = !drop && unfuse_below > 0 && M / 64 < unfuse_below;
+    if (!no_fuse && !small && attn_block_supported(p, user_mask, dtype, C, heads)) {
         const bool with_fc1 = fc1_done && !no_fc1 && dtype_half(dtype) && C >= 32;
         if (fc1_done) *fc1_done = with_fc1;
         return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st, drop);
