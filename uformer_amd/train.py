@@ -288,7 +288,10 @@ class UformerTape:
     def __init__(self, sd: Dict[str, Tensor], cfg, dtype: torch.dtype = torch.float32, drop_scales: Optional[Tensor] = None,
                  recompute: Optional[bool] = None, on_stage_done=None):
         self.sd, self.cfg, self.T, self.drop = sd, cfg, dtype, drop_scales
-        self.recompute = (dtype in (torch.bfloat16, torch.float16)) if recompute is None else recompute
+        if recompute is None and os.environ.get("UF_TRAIN_RECOMPUTE") is not None:       # A/B switch: 0 = keep every intermediate, 1 = always recompute
+            recompute = os.environ["UF_TRAIN_RECOMPUTE"] != "0"
+        # None = decided in forward() from the batch and the free device memory (2-byte operand types; f32 always keeps its intermediates)
+        self.recompute = recompute if (recompute is not None or dtype in (torch.bfloat16, torch.float16)) else False
         self.on_stage_done = on_stage_done          # callback({name: gradient}) for every group of parameters whose gradients are final, in reverse-sweep order
 
     def forward(self, img: Tensor) -> Tensor:
@@ -296,6 +299,14 @@ class UformerTape:
         sd, cfg, T = self.sd, self.cfg, self.T
         B, _, H, W = img.shape
         self.B, self.H = B, H
+        if self.recompute is None:
+            # Keeping every intermediate of the op-by-op forward costs ~60 bytes per token x channel of every block (measured: 56 GB for
+            # Uformer-B 256^2 at batch 32 against 17 GB) and saves the recomputation in the backward: 332 vs 314 img/s on an MI355X
+            # (profiles/r03_recompute_ab.txt).  288 GB of HBM is there to be used: keep them while that is under half of the free memory.
+            dims, div = cfg.stage_dims(), cfg.stage_res_div()
+            need = 60 * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
+            free = torch.cuda.mem_get_info(img.device)[0]
+            self.recompute = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 327 vs 330 img/s): keep the small one
         shifts = cfg.block_shifts()
         res = self.res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
         first = [sum(cfg.depths[:s]) for s in range(9)]
