@@ -174,9 +174,39 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     return y, saved
 
 
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
+class _Side:
+    """Weight-gradient jobs of a block on a side stream (nothing downstream in the block reads them), as the C++ block backward does
+    (UF_BWD_STREAMS=1 turns it off): ``run(fn)`` orders the side stream behind everything enqueued on the caller's stream so far and runs
+    ``fn`` on it; ``join()`` makes the caller's stream wait for the side stream.  Allocations made inside ``run`` belong to the side
+    stream; inputs stay referenced by the caller until after ``join()``, so the caching allocator cannot hand them out early."""
+
+    def __init__(self, device):
+        self.on = os.environ.get("UF_BWD_STREAMS", "2") != "1"
+        if self.on:
+            key = str(device)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+            self.side, self.cur = _SIDE_STREAMS[key], torch.cuda.current_stream(device)
+
+    def run(self, fn):
+        if not self.on:
+            return fn()
+        self.side.wait_stream(self.cur)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self):
+        if self.on:
+            self.cur.wait_stream(self.side)
+
+
 def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     """dy: (B, L, C) gradient of the block output -> (dx, gradients keyed like the reference's named_parameters())."""
     p, prefix, heads, shift, T = sv["p"], sv["prefix"], sv["heads"], sv["shift"], sv["T"]
+    side = _Side(dy.device)
     B, L, C = sv["shape"]
     H = W = int(math.sqrt(L))
     M, hd = B * L, C // heads
@@ -185,31 +215,34 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     dyf = dy.reshape(M, C).float()
     _, dyT = ops.grad_fork(dyf, None, sv["s2"], B, H, W, T)                  # gradient entering the (scaled) LeFF branch, as a GEMM operand
     # LeFF: linear2 -> GELU -> depthwise -> GELU -> linear1                                   (model.py:666-685)
-    g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = ops.linear_wgrad(dyT, sv["g2"])
+    g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = side.run(lambda: ops.linear_wgrad(dyT, sv["g2"]))
     pk: BlockPack = sv["pk"]
     dc = ops.linear_mul_dgelu(dyT, pk.w2_t, _zeros(4 * C, dyT.device), sv["c"].reshape(M, 4 * C)).reshape(B, H, W, 4 * C)   # dY W2, times GELU'(c)
-    dw9, g[prefix + "mlp.dwconv.0.bias"] = ops.dwconv3x3_wgrad(sv["h1"], dc)
-    g[prefix + "mlp.dwconv.0.weight"] = dw9.t().reshape(4 * C, 1, 3, 3)
+    def _dw():
+        dw9, db = ops.dwconv3x3_wgrad(sv["h1"], dc)
+        return dw9.t().reshape(4 * C, 1, 3, 3), db
+    g[prefix + "mlp.dwconv.0.weight"], g[prefix + "mlp.dwconv.0.bias"] = side.run(_dw)
     da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
-    g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = ops.linear_wgrad(da1, sv["z"])
+    g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = side.run(lambda: ops.linear_wgrad(da1, sv["z"]))
     dz = _input_grad(da1, pk.w1_t)
     dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W)
     # attention half: proj -> attention -> qkv -> (+modulator) -> partition/roll -> LN1              (model.py:951-986)
     # dx1 += dy (the residual), and the (scaled) gradient entering the attention branch in window order, in one pass
     dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
-    g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = ops.linear_wgrad(dyw, sv["o"])
+    g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = side.run(lambda: ops.linear_wgrad(dyw, sv["o"]))
     do = _input_grad(dyw, pk.wp_t)
     dqkv, dbias = ops.window_attention_bwd_qkv(sv["q"], sv["k"], sv["vt"], pk.bias, do, H, W, shift)    # heads merged, dq times the query scale
-    g[prefix + "attn.relative_position_bias_table"] = ops.rpb_table_grad(dbias)       # gather over the pairs of each table entry: deterministic
+    g[prefix + "attn.relative_position_bias_table"] = side.run(lambda: ops.rpb_table_grad(dbias))   # gather over the pairs of each table entry: deterministic
     nW = M // 64
-    dWqkv, dbqkv = ops.linear_wgrad(dqkv, sv["xn"])
+    dWqkv, dbqkv = side.run(lambda: ops.linear_wgrad(dqkv, sv["xn"]))
     g[prefix + "attn.qkv.to_q.weight"], g[prefix + "attn.qkv.to_kv.weight"] = dWqkv[:C], dWqkv[C:]
     g[prefix + "attn.qkv.to_q.bias"], g[prefix + "attn.qkv.to_kv.bias"] = dbqkv[:C], dbqkv[C:]
     dxn = _input_grad(dqkv, pk.wqkv_t)
     if sv["mod"]:                                                           # the (64, C) table is added to every window
-        g[prefix + "modulator.weight"] = ops.rows_sum(dxn.reshape(nW, 64 * C)).reshape(64, C)
+        g[prefix + "modulator.weight"] = side.run(lambda: ops.rows_sum(dxn.reshape(nW, 64 * C)).reshape(64, C))
     # LN1 backward reads dxn in window order (window_reverse + roll back folded in) and adds the residual path's gradient
     dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"] = ops.layernorm_bwd_fused(sv["x2"], f("norm1.weight"), dxn, B, H, W, add=dx1, windowed=True, shift=shift)
+    side.join()
     return dx.reshape(B, L, C), g
 
 
