@@ -271,6 +271,13 @@ int uf_window_attention_bwd_qkv(const void* q, const void* k, const void* vt, co
 size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype);
 int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, float* dbias, int B, int H, int W, int C,
                        uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* the whole backward of the LeFF's depthwise conv behind its GELU in ONE pass over dc (model.py:657-660, autograd of
+ * `self.dwconv(x)` after `self.linear1(x)`): da T[B][H][W][C] = what uf_dwconv3x3_mul_dgelu(dc, w9_flipped, pre) writes (bit-identical; f32: to an ulp),
+ * dw9 / dbias = what uf_dwconv3x3_wgrad(h = T(GELU(pre)), dc) computes (another summation order: equal to rounding) -- the conv input
+ * h is recomputed from the pre-activation instead of being read, dc is read once.  Tensors under 4 GiB, H multiple of 4. */
+size_t uf_dwconv3x3_bwd_workspace_bytes(int C, uf_dtype dtype);
+int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const void* pre, void* da, float* dw9, float* dbias,
+                     int B, int H, int W, int C, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- a15: reductions and patch gathers of the backward (no ATen glue) -------------------------------------------------------
  * out f32[N] = sum over the M rows of X T[M][ld]: the modulator gradient (model.py:966-969: the (64,C) table is added to every

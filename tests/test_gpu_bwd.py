@@ -78,6 +78,33 @@ def test_dwconv3x3_backward(dtype, B, H, W, C):
 
 
 @pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32), (5, 4, 8, 2048), (2, 64, 64, 96), (70, 8, 8, 16)])
+def test_dwconv3x3_fused_backward(dtype, B, H, W, C):
+    """uf_dwconv3x3_bwd (one pass over dc; h1 recomputed from the pre-activation) against the two kernels it replaces: the input gradient
+    bit-identical to uf_dwconv3x3_mul_dgelu (f32: to an ulp), the tap / bias gradients equal to uf_dwconv3x3_wgrad(GELU(pre), dc) up to summation order,
+    and against the oracle's closed forms; run-to-run bit-identical (no atomics)."""
+    from uformer_amd import ops
+    pre = torch.randn(B, H, W, C, generator=g(40)).to(dtype).cuda()
+    dc = torch.randn(B, H, W, C, generator=g(41)).to(dtype).cuda()
+    w = torch.randn(C, 1, 3, 3, generator=g(42)) * 0.3
+    w9 = w.reshape(C, 9).t().contiguous().cuda()
+    flip = w9.flip(0).contiguous()
+    h1 = ops.gelu(pre)                                                                # what the forward stored: T(GELU(pre as stored))
+    da, dw9, db = ops.dwconv3x3_bwd(dc, flip, pre)
+    da_2k = ops.dwconv3x3_mul_dgelu(dc, flip, pre)
+    # 2-byte operands: bit-identical.  f32: GELU' is inlined into another instruction stream (fma contraction may differ by an ulp)
+    same = torch.equal(da, da_2k) if dtype != torch.float32 else rel(da, da_2k.cpu()) < 1e-6
+    assert same, f"da differs from uf_dwconv3x3_mul_dgelu: max {(da.float() - da_2k.float()).abs().max().item():.3e}"
+    dw9_2k, db_2k = ops.dwconv3x3_wgrad(h1, dc)
+    assert rel(dw9, dw9_2k.cpu()) < 2e-5, f"dw9 vs two-kernel form: {rel(dw9, dw9_2k.cpu()):.3e}"
+    assert rel(db, db_2k.cpu()) < 2e-5, f"db vs two-kernel form: {rel(db, db_2k.cpu()):.3e}"
+    _, rdw, rdb = OB.dwconv3x3_bwd(h1.float().cpu(), w, dc.float().cpu())
+    assert rel(dw9, rdw.reshape(C, 9).t()) < pick(dtype, 2e-4, 2e-3) and rel(db, rdb) < pick(dtype, 2e-4, 2e-3)
+    da2, dw9b, dbb = ops.dwconv3x3_bwd(dc, flip, pre)
+    assert torch.equal(da, da2) and torch.equal(dw9, dw9b) and torch.equal(db, dbb)
+
+
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512)])
 def test_linear_wgrad_and_input_grad(dtype, M, N, K):
     """dW = dY^T X, db = column sums (token-split MFMA kernel, two-stage sums) and dX = dY W through the forward GEMM."""

@@ -96,6 +96,8 @@ SIGNATURES = {
     "uf_window_attention_bwd_qkv": (I, [P, P, P, P, P, I, P, I, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),
     "uf_dwconv3x3_wgrad_workspace_bytes": (c_size_t, [I, I]),
     "uf_dwconv3x3_wgrad": (I, [P, P, P, P, I, I, I, I, I, P, c_size_t, P]),
+    "uf_dwconv3x3_bwd_workspace_bytes": (c_size_t, [I, I]),
+    "uf_dwconv3x3_bwd": (I, [P, P, P, P, P, P, I, I, I, I, I, P, c_size_t, P]),
     "uf_dwconv_linear2_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "uf_block_workspace_bytes": (c_size_t, [I, I, I]),
     "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),

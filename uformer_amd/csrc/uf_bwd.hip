@@ -299,6 +299,214 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_finalize(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Depthwise 3x3 backward in ONE pass over dc (the gradient at the stencil's output):
+//   da1 = T(stencil(dc; flipped taps)) * GELU'(a1)       -- what uf_dwconv3x3_mul_dgelu writes, same FMA order (2-byte types: bit-identical)
+//   dw[a][b][c], db[c]                                      -- what uf_dwconv3x3_wgrad computes from h1 and dc
+// The tap gradient is taken centred on the thread's own pixels:
+//   dw[a][b] = sum_{y,x} dc[y][x] h1[y+a-1][x+b-1] = sum_{y',x'} h1[y'][x'] dc[y'-a+1][x'-b+1],
+// so the dc neighbours are the ones the input-gradient stencil loads anyway, and h1 = T(GELU(a1 as stored)) -- exactly what the
+// forward wrote -- is recomputed from the pre-activation the thread holds for GELU'.  h1 and dc are not read a second time (the
+// separate tap-gradient kernel moved 2 x M x 4C operands per block again and wrote 42 MB of per-thread partial sums per call).
+// A workgroup = `cg` channel groups (N channels each) x 256/cg pixel columns, strips of R rows; it walks the (image, strip, x)
+// positions with a fixed stride and keeps its channels, so the 10 x N accumulators stay in registers; at the end the pixel threads
+// of a channel group meet in LDS (fixed order) and ONE partial per workgroup and channel goes to the workspace;
+// dwconv3x3_bwd_finalize adds the workgroups in order.  Bit-reproducible, no atomics.
+// ---------------------------------------------------------------------------------------------------------------
+// N channels of the operand type as one load / store: 16 bytes (8 x 2-byte, 4 x f32) or 8 bytes (4 x 2-byte)
+template <typename T, int N> struct Chunk;
+template <typename T> struct Chunk<T, 8> {
+    static_assert(sizeof(T) == 2, "8 channels of a 2-byte type");
+    using Raw = u32x4;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { unpack8<T>(r, f); }
+    static __device__ __forceinline__ Raw pack(const float* f) { return pack8<T>(f); }
+};
+template <typename T> struct Chunk<T, 4> {
+    using Raw = typename std::conditional<sizeof(T) == 2, u32x2, u32x4>::type;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        if constexpr (sizeof(T) == 2) { unpack2<T>(r[0], f[0], f[1]); unpack2<T>(r[1], f[2], f[3]); }
+        else { f[0] = __uint_as_float(r[0]); f[1] = __uint_as_float(r[1]); f[2] = __uint_as_float(r[2]); f[3] = __uint_as_float(r[3]); }
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) {
+        if constexpr (sizeof(T) == 2) return Raw{pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3])};
+        else return Raw{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+};
+template <typename T, int N> __device__ __forceinline__ void round_t(float* f) {   // to the operand type and back (what a later pass would read)
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int i = 0; i < N; i += 2) unpack2<T>(pack2<T>(f[i], f[i + 1]), f[i], f[i + 1]);
+    }
+}
+
+// byte offsets are 32-bit (the launcher checks the tensor is under 4 GiB): one VGPR per address next to the uniform base pointer
+template <typename T, int N, int R>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_kernel(const T* __restrict__ dc, const float* __restrict__ w9f, const T* __restrict__ a1, T* __restrict__ da1,
+                                                               float* __restrict__ partial, int B, int H, int W, int C, int cg_log2) {
+    using CH = Chunk<T, N>;
+    using Raw = typename CH::Raw;
+    __shared__ float red[256][N + 1];
+    const int tid = threadIdx.x;
+    const int cg = 1 << cg_log2, cv = C / N, cb = cv >> cg_log2, px = 256 >> cg_log2;
+    const int cgi = tid & (cg - 1), pi = tid >> cg_log2;
+    const int c = (((int)blockIdx.x % cb) * cg + cgi) * N;
+    const int strips = H / R;
+    const int P = B * strips * W;
+    const int pstep = ((int)gridDim.x / cb) * px;
+    const unsigned rowb = (unsigned)W * C * (unsigned)sizeof(T), pixb = (unsigned)C * (unsigned)sizeof(T);
+    const char* dcb = reinterpret_cast<const char*>(dc);
+    const char* a1b = reinterpret_cast<const char*>(a1);
+    char* dab = reinterpret_cast<char*>(da1);
+    float wacc[10][N];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < N; ++i) wacc[t][i] = 0.f;
+    for (int pos = ((int)blockIdx.x / cb) * px + pi; pos < P; pos += pstep) {
+        const int xw = pos % W, rest = pos / W;
+        const int y0 = (rest % strips) * R, b = rest / strips;
+        const unsigned o00 = ((unsigned)(b * H + y0) * W + xw) * pixb + (unsigned)c * (unsigned)sizeof(T);   // this thread's first pixel
+        Raw araw[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) araw[r] = *reinterpret_cast<const Raw*>(a1b + (o00 + r * rowb));
+        float hc[R][N], acc[R][N];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            CH::unpack(araw[r], hc[r]);
+            gelu_n<T, N>(hc[r]);
+            round_t<T, N>(hc[r]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[r][i] = 0.f;
+        }
+        // rows y0 - 1 and y0 + R clamped into the image (their values are masked below)
+        const unsigned otop = y0 > 0 ? o00 - rowb : o00, obot = y0 + R < H ? o00 + R * rowb : o00 + (R - 1) * rowb;
+        const float mtop = y0 > 0 ? 1.0f : 0.0f, mbot = y0 + R < H ? 1.0f : 0.0f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ixr = xw + kx - 1;
+            const float mx = (ixr >= 0 && ixr < W) ? 1.0f : 0.0f;
+            const int dxp = ixr < 0 ? 0 : (ixr >= W ? 0 : kx - 1);     // clamped column, relative to xw
+            const unsigned oshift = (unsigned)(dxp * (int)pixb);
+            // the taps are the same in every position step: re-read them (L1) through an offset the compiler cannot see through, or it
+            // keeps all 9 N of them live across the loop next to the 10 N accumulators and spills
+            int wo = kx * C + c;
+            asm volatile("" : "+v"(wo));
+            float wk[3][N];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w9f + (size_t)(ky * 3) * C + wo);
+                static_assert(N == 4 || N == 8, "4 or 8 channels per thread");
+                wk[ky][0] = wv[0] * mx; wk[ky][1] = wv[1] * mx; wk[ky][2] = wv[2] * mx; wk[ky][3] = wv[3] * mx;
+                if constexpr (N == 8) {
+                    const f32x4 wu = *reinterpret_cast<const f32x4*>(w9f + (size_t)(ky * 3) * C + wo + 4);
+                    wk[ky][4] = wu[0] * mx; wk[ky][5] = wu[1] * mx; wk[ky][6] = wu[2] * mx; wk[ky][7] = wu[3] * mx;
+                }
+            }
+            Raw fr[R + 2];
+#pragma unroll
+            for (int r = -1; r <= R; ++r) {
+                const unsigned o = (r == -1 ? otop : (r == R ? obot : o00 + r * rowb)) + oshift;
+                fr[r + 1] = *reinterpret_cast<const Raw*>(dcb + o);
+            }
+#pragma unroll
+            for (int r = -1; r <= R; ++r) {                 // dc row y0 + r feeds output rows r + 1 - ky
+                float f[N];
+                CH::unpack(fr[r + 1], f);
+                if (r == -1) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) f[i] *= mtop;
+                }
+                if (r == R) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) f[i] *= mbot;
+                }
+                if (kx == 1 && r >= 0 && r < R) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) wacc[9][i] += f[i];
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = r + 1 - ky;
+                    if (orow < 0 || orow >= R) continue;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[orow][i] = fmaf(f[i], wk[ky][i], acc[orow][i]);
+                }
+                if (kx != 1) {                               // the column mask of the tap gradient (the stencil has it inside wk)
+#pragma unroll
+                    for (int i = 0; i < N; ++i) f[i] *= mx;
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = r + 1 - ky;
+                    if (orow < 0 || orow >= R) continue;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) wacc[(2 - ky) * 3 + (2 - kx)][i] = fmaf(hc[orow][i], f[i], wacc[(2 - ky) * 3 + (2 - kx)][i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);              // one column tap at a time: all 3 (R + 2) loads hoisted = the register file
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float a[N];
+            CH::unpack(araw[r], a);
+            round_t<T, N>(acc[r]);
+#pragma unroll
+            for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
+            *reinterpret_cast<Raw*>(dab + (o00 + r * rowb)) = CH::pack(acc[r]);
+        }
+    }
+    // the pixel threads of a channel group meet in LDS: thread (cgi, i) adds its px partners in pixel order
+    float* out = partial + (size_t)blockIdx.x * 10 * cg * N;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[tid][i] = wacc[t][i];
+        __syncthreads();
+        if (tid < cg * N) {
+            const int g = tid / N, i = tid % N;
+            float s = 0.f;
+            for (int q = 0; q < px; ++q) s += red[q * cg + g][i];
+            out[t * cg * N + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// dw9[t][c] (t < 9) and dbias[c] (t == 9) = sum over the workgroups w = cblk, cblk + cb, ... of partial[w][t][c within the block].
+// 32 outputs per workgroup, 8 p-lanes per output (every 8th workgroup, in order), lane sums added in lane order: fixed order.
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_finalize(const float* __restrict__ partial, int blocks, int cb, int cgN, float* __restrict__ dw9,
+                                                             float* __restrict__ dbias, int C) {
+    __shared__ float sh[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int j = blockIdx.x * 32 + col;   // over 10 * C outputs
+    float s = 0.f;
+    int t = 0, c = 0;
+    if (j < 10 * C) {
+        t = j / C; c = j % C;
+        const int cblk = c / cgN, cl = c % cgN;
+        const float* src = partial + (size_t)t * cgN + cl;
+        const size_t wstride = (size_t)10 * cgN;
+        const int slots = blocks / cb;
+        int q = pl;
+        for (; q + 56 < slots; q += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[(size_t)((q + 8 * u) * cb + cblk) * wstride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; q < slots; q += 8) s += src[(size_t)(q * cb + cblk) * wstride];
+    }
+    sh[pl][col] = s;
+    __syncthreads();
+    if (pl == 0 && j < 10 * C) {
+        float r = sh[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) r += sh[k][col];
+        if (t < 9) dw9[(size_t)t * C + c] = r; else dbias[c] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // nn.Linear weight / bias gradients:  dW[n][k] = sum_m dY[m][n] X[m][k],  db[n] = sum_m dY[m][n]   (linear_bwd).
 // The contraction runs over TOKENS, so both MFMA operands need 8 consecutive tokens of ONE column per lane: a step
 // stages dY[32 tokens][64 n] and X[32 tokens][64 k] transposed into LDS ([column][token]) and each wave issues 2 x 2
@@ -864,6 +1072,55 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     return check_launch("dwconv3x3_wgrad_finalize");
 }
 
+// geometry of dwconv3x3_bwd_kernel for C channels: N channels per thread (2-byte operands: 4 = 8-byte loads at ~120 VGPRs, the default,
+// or 8 with UF_DWBWD_VEC=8 = 16-byte loads at the register limit; f32: 4), channel groups per workgroup (a power of two dividing C / N,
+// at most 32), workgroups (UF_DWBWD_BLOCKS, default 1024 = four per CU, rounded up to whole channel-block rounds)
+static void dw_bwd_geometry(int C, uf_dtype dtype, int* cg_log2, int* blocks, int* N_) {
+    static const int target = getenv("UF_DWBWD_BLOCKS") ? atoi(getenv("UF_DWBWD_BLOCKS")) : 0;
+    static const int vec8 = getenv("UF_DWBWD_VEC") ? atoi(getenv("UF_DWBWD_VEC")) == 8 : 0;
+    const int N = (dtype_half(dtype) && vec8 && C % 8 == 0) ? 8 : 4, cv = C / N;
+    int lg = 0;
+    while (lg < 5 && cv % (2 << lg) == 0) ++lg;
+    const int cb = cv >> lg, want = target > 0 ? target : (N == 8 ? 512 : 1024);
+    *cg_log2 = lg; *blocks = (want + cb - 1) / cb * cb; *N_ = N;
+}
+
+extern "C" size_t uf_dwconv3x3_bwd_workspace_bytes(int C, uf_dtype dtype) {
+    if (C <= 0 || !dtype_ok(dtype) || C % (dtype_half(dtype) ? 8 : 4)) return 0;
+    int lg, blocks, N;
+    dw_bwd_geometry(C, dtype, &lg, &blocks, &N);
+    return (size_t)blocks * 10 * (N << lg) * sizeof(float);
+}
+
+extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const void* pre, void* da, float* dw9, float* dbias, int B, int H, int W, int C,
+                                uf_dtype dtype, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(dc && w9_flipped && pre && da && dw9 && dbias && ws, UF_ERR_NULL, "uf_dwconv3x3_bwd: null pointer");
+    UF_REQUIRE(dtype_ok(dtype), UF_ERR_UNSUPPORTED, "uf_dwconv3x3_bwd: dtype %d", (int)dtype);
+    const int Nn = dtype_half(dtype) ? 8 : 4;
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % Nn == 0 && H % DWB_R == 0, UF_ERR_SHAPE,
+               "uf_dwconv3x3_bwd: B=%d H=%d W=%d C=%d (C multiple of %d, H multiple of %d)", B, H, W, C, Nn, DWB_R);
+    UF_REQUIRE((unsigned long long)B * H * W * C * dtype_size(dtype) < 0xffffffffULL, UF_ERR_SHAPE, "uf_dwconv3x3_bwd: tensor of 4 GiB or more: split the batch");
+    UF_REQUIRE(((uintptr_t)dc % 16) == 0 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)w9_flipped % 16) == 0, UF_ERR_ALIGN,
+               "uf_dwconv3x3_bwd: operands must be 16-byte aligned");
+    const size_t need = uf_dwconv3x3_bwd_workspace_bytes(C, dtype);
+    UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_dwconv3x3_bwd: workspace too small: %zu < %zu", ws_bytes, need);
+    int lg, blocks, N;
+    dw_bwd_geometry(C, dtype, &lg, &blocks, &N);
+    const int cb = (C / N) >> lg;
+    hipStream_t st = (hipStream_t)stream;
+#define UF_DWBWD_ARGS dim3(blocks), dim3(256), 0, st, (const TT*)dc, w9_flipped, (const TT*)pre, (TT*)da, (float*)ws, B, H, W, C, lg
+    if (dtype == UF_F32) { using TT = float; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
+    else if (dtype == UF_BF16 && N == 4) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
+    else if (dtype == UF_BF16) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 8, DWB_R>), UF_DWBWD_ARGS); }
+    else if (N == 4) { using TT = f16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
+    else { using TT = f16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 8, DWB_R>), UF_DWBWD_ARGS); }
+#undef UF_DWBWD_ARGS
+    int rc = check_launch("dwconv3x3_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(dwconv3x3_bwd_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks, cb, N << lg, dw9, dbias, C);
+    return check_launch("dwconv3x3_bwd_finalize");
+}
+
 static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullptr; return !off; }   // UF_WGRAD_V1=1: first version (A/B, tests)
 static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     const int T = (dtype_half(dtype) && wgrad_v2()) ? 128 : 64;
@@ -1082,6 +1339,64 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dcols
     }
 }
 
+// Token-layout (NHWC) fast paths: 8 channels per thread (Cin % 8 == 0 keeps the 8 inside one tap), 16-byte loads and stores.
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f) { Vec<T>::load(p, f); if constexpr (sizeof(T) == 4) Vec<T>::load(p + 4, f + 4); }
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* f) { Vec<T>::store(p, f); if constexpr (sizeof(T) == 4) Vec<T>::store(p + 4, f + 4); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_rows8_kernel(const float* __restrict__ x, int ld_x, T* __restrict__ cols, int ldc, int B, int H, int W, int Cin, int k,
+                                                           int stride, int pad, int Ho, int Wo) {
+    const int cv = ldc / 8, kk = k * k * Cin;
+    const long long total = (long long)B * Ho * Wo * cv;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int col = (int)(t % cv) * 8;
+        const long long m = t / cv;
+        float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (col < kk) {
+            const int tap = col / Cin, c = col - tap * Cin, ky = tap / k, kx = tap - ky * k;
+            const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((long long)Wo * Ho));
+            const int iy = oy * stride + ky - pad, ix = ox * stride + kx - pad;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) ld8<float>(x + ((size_t)(b * H + iy) * W + ix) * ld_x + c, f);
+        }
+        st8<T>(cols + (size_t)m * ldc + col, f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_rows8_kernel(const T* __restrict__ dcols, int ldc, float* __restrict__ dx, int ld_dx, int B, int H, int W, int Cin, int k,
+                                                           int stride, int pad, int Ho, int Wo, int accumulate) {
+    const int cv = Cin / 8;
+    const long long total = (long long)B * H * W * cv;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int c = (int)(t % cv) * 8, xx = (int)((t / cv) % W), yy = (int)((t / ((long long)cv * W)) % H), b = (int)(t / ((long long)cv * W * H));
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ky = 0; ky < k; ++ky) {                                            // same (ky, kx) order as the scalar kernel: bit-identical sums
+            const int ny = yy + pad - ky;
+            if (ny < 0 || ny % stride) continue;
+            const int oy = ny / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int nx = xx + pad - kx;
+                if (nx < 0 || nx % stride) continue;
+                const int ox = nx / stride;
+                if (ox >= Wo) continue;
+                float f[8];
+                ld8<T>(dcols + ((size_t)(b * Ho + oy) * Wo + ox) * ldc + (ky * k + kx) * Cin + c, f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += f[e];
+            }
+        }
+        float* o = dx + ((size_t)(b * H + yy) * W + xx) * ld_dx + c;
+        if (accumulate) {
+            float a[8];
+            ld8<float>(o, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+        }
+        st8<float>(o, s);
+    }
+}
+
 int grid1d(long long n) {
     long long g = (n + 1023) / 1024;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -1117,6 +1432,10 @@ extern "C" int uf_im2col(const float* x, int ld_x, void* cols, int ldc, int B, i
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long long total = (long long)B * Ho * Wo * ldc;
     hipStream_t st = (hipStream_t)stream;
+    if (!nchw && Cin % 8 == 0 && ldc % 8 == 0 && ld_x % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)cols % 16) == 0) {
+        UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(im2col_rows8_kernel<TT>, dim3(grid1d(total / 8)), dim3(256), 0, st, x, ld_x, (TT*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo));
+        return check_launch("im2col");
+    }
     UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(im2col_kernel<TT>, dim3(grid1d(total)), dim3(256), 0, st, x, ld_x, (TT*)cols, ldc, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw));
     return check_launch("im2col");
 }
@@ -1128,6 +1447,10 @@ extern "C" int uf_col2im(const void* dcols, int ldc, float* dx, int ld_dx, int B
     const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
     const long long total = (long long)B * H * W * Cin;
     hipStream_t st = (hipStream_t)stream;
+    if (!nchw && Cin % 8 == 0 && ldc % 8 == 0 && ld_dx % 4 == 0 && ((uintptr_t)dx % 16) == 0 && ((uintptr_t)dcols % 16) == 0) {
+        UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(col2im_rows8_kernel<TT>, dim3(grid1d(total / 8)), dim3(256), 0, st, (const TT*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, accumulate));
+        return check_launch("col2im");
+    }
     UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(col2im_kernel<TT>, dim3(grid1d(total)), dim3(256), 0, st, (const TT*)dcols, ldc, dx, ld_dx, B, H, W, Cin, k, stride, pad, Ho, Wo, nchw, accumulate));
     return check_launch("col2im");
 }

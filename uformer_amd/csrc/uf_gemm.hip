@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         constexpr int SROWT = WTM * (int)sizeof(T) + 16;  // transposed [n][m] orientation (V^T)
         constexpr int STG = (WTM * SROW > WTN * SROWT) ? WTM * SROW : WTN * SROWT;
         static_assert(4 * STG <= 2 * BUF_BYTES, "staging does not fit the main-loop LDS");
+        static_assert(sizeof(T) != 2 || 4 * STG <= BUF_BYTES, "2-byte types: the staging must fit ONE buffer (single-buffer launches when K is one tile)");
         char* stg = smem + wave * STG;
         const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
         const int C = p.heads * p.hd;
@@ -326,10 +327,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 
 template <typename T, int BN, int WGM, int WGN, int AL, int EP>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem = 2 * (BM + BN) * ROWB;
+    constexpr int smem2 = 2 * (BM + BN) * ROWB;
     auto kern = gemm_kernel<T, BN, WGM, WGN, AL, EP>;
     static bool lds_done[64] = {};
-    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "gemm")) return rc;
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem2, lds_done, "gemm")) return rc;
+    // K within ONE tile (K <= 64 for the 2-byte types: every projection of the 32- and 64-channel stages, the ones with the most tokens):
+    // the second LDS buffer is never touched, and without it 3-4 workgroups fit a CU instead of 2 -- these launches are streams of
+    // short load -> MFMA -> store chains, bound by how many of them are in flight.  (The staged epilogue of the 2-byte types fits one
+    // buffer; the f32 one does not.)  UF_GEMM_LDS2=1 keeps both buffers, for A/B runs.
+    static const bool lds2 = getenv("UF_GEMM_LDS2") != nullptr;
+    constexpr int BKE = 8 * (16 / (int)sizeof(T));
+    const int smem = (sizeof(T) == 2 && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;
     const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";

@@ -47,6 +47,7 @@ void op_scratch_bytes(int B, int H, int W, int C, int heads, uf_dtype dtype, siz
     auto mx = [&](size_t v) { if (v > s) s = v; };
     mx(uf_layernorm_bwd_workspace_bytes(M, C));
     mx(uf_window_attention_bwd_workspace_bytes(M / 64, heads));
+    mx(uf_dwconv3x3_bwd_workspace_bytes(4 * C, dtype));
     *main_bytes = s;
     s = 0;
     mx(uf_linear_wgrad_workspace_bytes(M, C, 4 * C));
@@ -165,11 +166,18 @@ int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const flo
     UF_TRY(qs.fork());
     UF_TRY(uf_linear_wgrad(pl.tA, C, pl.g2, C4, g->w2, g->b2, M, C, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_mul_dgelu(pl.tA, p->w2_t, pl.zero, pl.c, pl.dc, M, C4, C, dtype, st));                               // dc = (dyT W2) GELU'(c)
-    UF_TRY(qs.fork());
-    UF_TRY(uf_dwconv3x3_wgrad(pl.h1, pl.dc, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
-    hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)sw, (const float*)pl.dw9, g->wdw, C4);
-    UF_TRY(check_launch("taps_to_param"));
-    UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.da1, B, H, W, C4, dtype, st));                            // da1
+    static const bool dw_fused = !(getenv("UF_DW_BWD_FUSED") && atoi(getenv("UF_DW_BWD_FUSED")) == 0);
+    if (dw_fused) {   // da1 and the tap / bias gradients in one pass over dc (h1 recomputed from a1); the taps come out on the main queue
+        UF_TRY(uf_dwconv3x3_bwd(pl.dc, p->wdw9_flip, pl.a1, pl.da1, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch, pl.scratch_bytes, st));
+        hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)pl.dw9, g->wdw, C4);
+        UF_TRY(check_launch("taps_to_param"));
+    } else {
+        UF_TRY(qs.fork());
+        UF_TRY(uf_dwconv3x3_wgrad(pl.h1, pl.dc, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
+        hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)sw, (const float*)pl.dw9, g->wdw, C4);
+        UF_TRY(check_launch("taps_to_param"));
+        UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.da1, B, H, W, C4, dtype, st));                        // da1
+    }
     UF_TRY(qs.fork());
     UF_TRY(uf_linear_wgrad(pl.da1, C4, pl.z, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_fwd(pl.da1, p->w1_t, pl.zero, pl.tE, M, C, C4, 0, dtype, st));                                        // dz

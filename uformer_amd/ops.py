@@ -434,6 +434,25 @@ def dwconv3x3_wgrad(h: Tensor, dc: Tensor):
     return dw9, db
 
 
+def dwconv3x3_bwd(dc: Tensor, w9_flipped: Tensor, pre: Tensor):
+    """Whole backward of the LeFF depthwise conv behind its GELU, one pass over dc (model.py:657-660): returns (da = stencil(dc; flipped
+    taps) * GELU'(pre) -- as dwconv3x3_mul_dgelu --, dw9 (9,C), db (C,) -- as dwconv3x3_wgrad(GELU(pre), dc))."""
+    _dev(dc, w9_flipped, pre)
+    dt = uf_dtype(dc.dtype)
+    dc, pre = _c(dc), _c(pre, dc.dtype)
+    B, H, W, Cc = dc.shape
+    da = torch.empty_like(dc)
+    dw9 = torch.empty(9, Cc, dtype=torch.float32, device=dc.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=dc.device)
+    lib = _lib.load()
+    nbytes = lib.uf_dwconv3x3_bwd_workspace_bytes(Cc, dt)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dc.device)
+    with torch.cuda.device(dc.device):
+        _lib.check(lib.uf_dwconv3x3_bwd(_ptr(dc), _ptr(_c(w9_flipped, torch.float32)), _ptr(pre), _ptr(da), _ptr(dw9), _ptr(db), B, H, W, Cc, dt,
+                                        _ptr(ws), nbytes, _stream()), "uf_dwconv3x3_bwd")
+    return da, dw9, db
+
+
 def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, x: Tensor) -> Tensor:
     """x + linear2(GELU(dwconv3x3(h1))) (model.py:674-683, :987).  h1 T(B,H,W,4C); x f32 (B*H*W, C); returns new x."""
     _dev(h1, w9, bdw, w2, b2, x)

@@ -174,7 +174,8 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     return y, saved
 
 
-_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+_SIDE_STREAMS: Dict[str, list] = {}
+_DW_BWD_FUSED = os.environ.get("UF_DW_BWD_FUSED", "1") != "0"      # 0: the two-kernel form (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad), for A/B runs
 
 
 class _Side:
@@ -184,23 +185,28 @@ class _Side:
     stream; inputs stay referenced by the caller until after ``join()``, so the caching allocator cannot hand them out early."""
 
     def __init__(self, device):
-        self.on = os.environ.get("UF_BWD_STREAMS", "2") != "1"
+        n = int(os.environ.get("UF_BWD_STREAMS", "2"))           # 1: off;  2: one side stream;  3+: jobs alternate over n - 1 side streams
+        self.on = n > 1
         if self.on:
             key = str(device)
-            if key not in _SIDE_STREAMS:
-                _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-            self.side, self.cur = _SIDE_STREAMS[key], torch.cuda.current_stream(device)
+            have = _SIDE_STREAMS.setdefault(key, [])
+            while len(have) < n - 1:
+                have.append(torch.cuda.Stream(device=device))
+            self.sides, self.cur, self.k = have[:n - 1], torch.cuda.current_stream(device), 0
 
     def run(self, fn):
         if not self.on:
             return fn()
-        self.side.wait_stream(self.cur)
-        with torch.cuda.stream(self.side):
+        side = self.sides[self.k % len(self.sides)]
+        self.k += 1
+        side.wait_stream(self.cur)
+        with torch.cuda.stream(side):
             return fn()
 
     def join(self):
         if self.on:
-            self.cur.wait_stream(self.side)
+            for side in self.sides:
+                self.cur.wait_stream(side)
 
 
 def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
@@ -218,11 +224,16 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = side.run(lambda: ops.linear_wgrad(dyT, sv["g2"]))
     pk: BlockPack = sv["pk"]
     dc = ops.linear_mul_dgelu(dyT, pk.w2_t, _zeros(4 * C, dyT.device), sv["c"].reshape(M, 4 * C)).reshape(B, H, W, 4 * C)   # dY W2, times GELU'(c)
-    def _dw():
-        dw9, db = ops.dwconv3x3_wgrad(sv["h1"], dc)
-        return dw9.t().reshape(4 * C, 1, 3, 3), db
-    g[prefix + "mlp.dwconv.0.weight"], g[prefix + "mlp.dwconv.0.bias"] = side.run(_dw)
-    da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
+    if _DW_BWD_FUSED:      # flipped-tap stencil times GELU'(a1) AND the tap / bias gradients, one pass over dc (h1 recomputed from a1)
+        da1, dw9, g[prefix + "mlp.dwconv.0.bias"] = ops.dwconv3x3_bwd(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C))
+        da1 = da1.reshape(M, 4 * C)
+        g[prefix + "mlp.dwconv.0.weight"] = dw9.t().reshape(4 * C, 1, 3, 3)
+    else:
+        def _dw():
+            dw9, db = ops.dwconv3x3_wgrad(sv["h1"], dc)
+            return dw9.t().reshape(4 * C, 1, 3, 3), db
+        g[prefix + "mlp.dwconv.0.weight"], g[prefix + "mlp.dwconv.0.bias"] = side.run(_dw)
+        da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
     g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = side.run(lambda: ops.linear_wgrad(da1, sv["z"]))
     dz = _input_grad(da1, pk.w1_t)
     dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W)
