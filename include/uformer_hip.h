@@ -234,6 +234,11 @@ int uf_linear_pre_gelu_fwd(const void* A, const void* W, const float* bias, void
                            uf_dtype dtype, void* stream);
 int uf_linear_mul_dgelu(const void* A, const void* W, const float* bias, const void* pre, void* out, int M, int N, int K,
                         uf_dtype dtype, void* stream);
+/* out f32[tok][N] = resid[tok][N] + scale[image of tok] * (A W^T + bias); tok = the token of window row m when `windowed` (window_reverse +
+ * roll back by `shift`), else m.  The attention projection / linear2 of a block with `x + drop_path(...)` (model.py:975-987) in the GEMM's
+ * store: scale f32[B] = bernoulli(keep) / keep per sample, or NULL.  A T[B*H*W][K], W T[N][K]; resid may alias out. */
+int uf_linear_residual_fwd(const void* A, const void* W, const float* bias, const float* resid, float* out, const float* scale,
+                           int B, int H, int Wd, int N, int K, int windowed, int shift, uf_dtype dtype, void* stream);
 /* nn.LayerNorm(C) backward over rows of the f32 stream: dx f32[rows][ld_dx]; dgamma, dbeta f32[C] are OVERWRITTEN
  * with the sums over all rows.  C in {16,32,64,128,256,512,1024}. */
 size_t uf_layernorm_bwd_workspace_bytes(int rows, int C);
@@ -337,6 +342,8 @@ typedef struct uf_block_train_params {
     const float* wdw9;  const float* wdw9_flip;  const float* bdw;     /* (9,4C) taps, the same with the tap axis reversed, (4C) */
     const void* w2_t;            /* T (4C,C): mlp.linear2.0.weight transposed */
     int32_t shift, heads;
+    const void* w2;              /* T (C,4C): mlp.linear2.0.weight as is -- read only by callers that run the op-by-op forward with this pack
+                                  * (uformer_amd/train.py, stored-intermediates form); the block backward entry points do not touch it */
 } uf_block_train_params;
 /* f32 outputs, OVERWRITTEN, in the layouts of the reference's parameters */
 typedef struct uf_block_grads {

@@ -1,0 +1,12 @@
+# Round 3: residual / DropPath in the GEMM store of the op-by-op forward: tests, timing, per-shape kernel table, idle time
+cd $GRAFT_REPO_ROOT
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+python -m pytest tests/test_gpu_bwd.py -m gpu -q -x 2>&1 | tail -3
+tb() { python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 $2 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$1', round(d['value'],1), 'img/s', round(d['ms_per_step'],1), 'ms', round(d['peak_mem_gb'],1), 'GB')"; }
+{
+tb "default"
+tb "default again" "--kernels-json $O/r03_train_kernels.json"
+} | tee $O/r03_train_resid.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d /tmp/ktt -o ktt -- python $R/scripts/train_bench.py --batch 32 --steps 2 --warmup 1 > $O/ktt.log 2>&1
+python $R/scripts/rocprof_summary.py /tmp/ktt/ktt_results.db $O/r03_train_stored3 | tail -2

@@ -50,8 +50,24 @@ if tl:
     gaps = [tl[i + 1][0] - tl[i][1] for i in range(len(tl) - 1)]
     small = [g for g in gaps if 0 <= g < 50_000]          # < 50 us: back-to-back launches inside a forward pass
     neg = sum(1 for g in gaps if g < 0)
+    # true idle time: the span minus the UNION of the busy intervals (kernels of several streams overlap), split at pauses > 5 ms
+    # (the host-side gaps between warm-up, timed loop and teardown are not launch gaps)
+    idle, span, cur_end, seg_start = 0, 0, None, None
+    for s0, e, _ in tl:
+        if cur_end is None:
+            cur_end, seg_start = e, s0
+            continue
+        if s0 > cur_end:
+            if s0 - cur_end > 5_000_000:
+                span += cur_end - seg_start
+                seg_start = s0
+            else:
+                idle += s0 - cur_end
+        cur_end = max(cur_end, e)
+    span += cur_end - seg_start
     with open(out + "_gaps.txt", "w") as f:
         msg = (f"dispatches {len(tl)}  kernel-busy {busy / 1e6:.3f} ms  gaps<50us: n={len(small)} total {sum(small) / 1e6:.3f} ms "
-               f"mean {sum(small) / max(1, len(small)) / 1e3:.2f} us  overlapping dispatches {neg}")
+               f"mean {sum(small) / max(1, len(small)) / 1e3:.2f} us  overlapping dispatches {neg}  "
+               f"active span {span / 1e6:.3f} ms of which no kernel running {idle / 1e6:.3f} ms ({100.0 * idle / max(1, span):.1f} %)")
         f.write(msg + "\n")
         print(msg)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--loss-scale", type=float, default=0.0, help="static loss scale (default: 65536 for f16 = GradScaler's initial scale, 1 otherwise)")
+    ap.add_argument("--kernels-json", default=None, help="also run ONE instrumented step (HIP events around every library launch) and write the per-(kernel, shape) table here")
     ap.add_argument("--sink", action="store_true", help="use the bucket-view gradient sink on one GPU too (exercises the overlapped path without a collective)")
     a = ap.parse_args()
     rank, local_rank, world = ud.init_process_group("nccl")
@@ -72,15 +73,22 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host_ms = (time.perf_counter() - t0) / a.steps * 1e3                            # the Python loop alone (enqueue); close to ms_per_step = host-bound
     torch.cuda.synchronize()
     ud.barrier()
     dt = ud.max_over_ranks(time.perf_counter() - t0, "cuda") / a.steps
     if rank == 0:
-        print(json.dumps({"metric": "training images/sec (fused fwd + recompute bwd + Charbonnier + AdamW kernels)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3,
+        print(json.dumps({"metric": "training images/sec (fused fwd + recompute bwd + Charbonnier + AdamW kernels)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": host_ms,
                           "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss_scale": ls, "loss": float(loss),
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "ranks": world,
                           "rank_devices": devices,
                           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}))
+    if a.kernels_json and rank == 0:
+        import bench
+        rows = bench.kernel_breakdown(None, None, 1, fn=step)
+        os.makedirs(os.path.dirname(os.path.abspath(a.kernels_json)), exist_ok=True)
+        with open(a.kernels_json, "w") as f:
+            json.dump(rows, f, indent=0)
     if world > 1:
         torch.distributed.destroy_process_group()
 

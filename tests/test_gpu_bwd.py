@@ -391,6 +391,29 @@ def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):
 
 
 @pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("shift,windowed", [(0, False), (0, True), (4, True)])
+def test_linear_residual_store(dtype, shift, windowed):
+    """uf_linear_residual_fwd: x + scale[image] * (a W^T + b) with window_reverse / roll back in the GEMM's store, against the f32
+    composition on the same (operand-rounded) inputs."""
+    from uformer_amd import ops
+    B, H, W, K, N = 3, 16, 24, 64, 32
+    M = B * H * W
+    a = torch.randn(M, K, generator=g(80)).to(dtype)
+    w = (torch.randn(N, K, generator=g(81)) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=g(82)) * 0.1
+    x = torch.randn(M, N, generator=g(83))
+    s = torch.tensor([0.0, 1.25, 1.25])
+    branch = a.float() @ w.float().t() + b
+    if windowed:
+        branch = ops.window_reverse(branch.reshape(-1, 8, 8, N).cuda(), 8, H, W, shift).reshape(M, N).cpu()
+    ref = x + branch * s.repeat_interleave(H * W).reshape(M, 1)
+    out = ops.linear_residual(a.cuda(), w.cuda(), b.cuda(), x.cuda(), s.cuda(), B, H, W, windowed=windowed, shift=shift)
+    assert rel(out, ref) < 2e-6
+    out1 = ops.linear_residual(a.cuda(), w.cuda(), b.cuda(), x.cuda(), None, B, H, W, windowed=windowed, shift=shift)
+    assert rel(out1, x + branch) < 2e-6                                            # no DropPath (eval, or rate 0)
+
+
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("shift", [0, 4])
 def test_backward_streaming_helpers(dtype, shift):
     """uf_residual_combine / uf_grad_fork / uf_qkv_grad_merge against the ATen sequences they replace (window_reverse + cast +

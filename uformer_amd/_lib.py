@@ -30,7 +30,7 @@ class BlockTrainParams(C.Structure):
     """``uf_block_train_params`` (include/uformer_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_w", "norm1_b", "norm2_w", "norm2_b", "modulator", "rpb_dense", "wqkv", "wqkv_t", "bqkv", "wproj", "wproj_t", "bproj",
-        "w1", "w1_t", "b1", "wdw9", "wdw9_flip", "bdw", "w2_t")] + [("shift", C.c_int32), ("heads", C.c_int32)]
+        "w1", "w1_t", "b1", "wdw9", "wdw9_flip", "bdw", "w2_t")] + [("shift", C.c_int32), ("heads", C.c_int32), ("w2", C.c_void_p)]
 
 
 class BlockRawParams(C.Structure):
@@ -86,6 +86,7 @@ SIGNATURES = {
     "uf_linear_mul_dgelu": (I, [P, P, P, P, P, I, I, I, I, P]),
     "uf_dwconv3x3_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "uf_dwconv3x3_mul_dgelu": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "uf_linear_residual_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),
     "uf_layernorm_bwd": (I, [P, I, P, P, I, P, I, P, P, I, I, P, c_size_t, P]),
     "uf_layernorm_bwd_fused": (I, [P, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),

@@ -1108,8 +1108,10 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
     dw_bwd_geometry(C, dtype, &lg, &blocks, &N);
     const int cb = (C / N) >> lg;
     hipStream_t st = (hipStream_t)stream;
+    static const bool rows2 = getenv("UF_DWBWD_ROWS") && atoi(getenv("UF_DWBWD_ROWS")) == 2;   // A/B (bf16): strips of 2 rows
 #define UF_DWBWD_ARGS dim3(blocks), dim3(256), 0, st, (const TT*)dc, w9_flipped, (const TT*)pre, (TT*)da, (float*)ws, B, H, W, C, lg
     if (dtype == UF_F32) { using TT = float; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
+    else if (dtype == UF_BF16 && N == 4 && rows2) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, 2>), UF_DWBWD_ARGS); }
     else if (dtype == UF_BF16 && N == 4) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
     else if (dtype == UF_BF16) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 8, DWB_R>), UF_DWBWD_ARGS); }
     else if (N == 4) { using TT = f16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }

@@ -102,7 +102,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
         int tok = m;
         if constexpr (EP == E_RES_WINREV) tok = window_row_to_token(m, p.H, p.W_, p.shift);
         const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + (size_t)tok * p.ldr + n);
-        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)tok * p.ldo + n) = r + (acc + b);
+        f32x4 v = acc + b;
+        if (p.scale) v *= p.scale[tok / p.hw];                // training: x + DropPath(branch), bernoulli(keep) / keep per sample
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)tok * p.ldo + n) = r + v;
     } else if constexpr (EP == E_STORE_R) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)m * p.ldo + n) = acc + b;
     } else {  // E_UPSAMPLE: n = (dy*2+dx)*Cout + co ; m = (b, y, x) on the (H, W) input grid
@@ -443,6 +445,19 @@ extern "C" int uf_linear_mul_dgelu(const void* A, const void* W, const float* bi
     p.A = A; p.lda = K; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.out = out; p.ldo = N; p.aux = const_cast<void*>(pre);
     UF_REQUIRE(out && pre, UF_ERR_NULL, "uf_linear_mul_dgelu: null pointer");
     return uf::launch_gemm(p, uf::A_PLAIN, uf::E_STORE_T_MUL_DGELU, dtype, (hipStream_t)stream);
+}
+
+// out f32[tok][N] = resid[tok][N] + scale[image of tok] * (A W^T + bias), tok = the token of window row m when `windowed` (window_reverse
+// + roll back), else m: the projection / linear2 GEMM of a block with the residual add (and DropPath) in its store   (model.py:975-987)
+extern "C" int uf_linear_residual_fwd(const void* A, const void* W, const float* bias, const float* resid, float* out, const float* scale, int B, int H, int Wd,
+                                      int N, int K, int windowed, int shift, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(resid && out, UF_ERR_NULL, "uf_linear_residual_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H > 0 && Wd > 0 && (!windowed || (H % 8 == 0 && Wd % 8 == 0)), UF_ERR_SHAPE, "uf_linear_residual_fwd: B=%d H=%d W=%d", B, H, Wd);
+    UF_REQUIRE(((uintptr_t)resid % 16) == 0 && ((uintptr_t)out % 16) == 0, UF_ERR_ALIGN, "uf_linear_residual_fwd: resid / out must be 16-byte aligned");
+    uf::GemmParams p{};
+    p.A = A; p.lda = K; p.W = W; p.bias = bias; p.M = B * H * Wd; p.N = N; p.K = K; p.out = out; p.ldo = N; p.resid = resid; p.ldr = N;
+    p.H = H; p.W_ = Wd; p.shift = shift; p.scale = scale; p.hw = H * Wd;
+    return uf::launch_gemm(p, uf::A_PLAIN, windowed ? uf::E_RES_WINREV : uf::E_RES, dtype, (hipStream_t)stream);
 }
 
 extern "C" int uf_qkv_fwd(const void* A, const void* Wqkv, const float* bqkv, void* q, void* k, void* vt, int M,

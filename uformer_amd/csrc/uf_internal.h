@@ -29,6 +29,7 @@ struct GemmParams {
     void* q; void* k; void* vt; int heads, hd; float qscale;
     int Cout;
     void* aux;                  // E_STORE_T_PRE_GELU: second output; E_STORE_T_MUL_DGELU: the pre-activation (read); ld = ldo
+    const float* scale; int hw; // E_RES / E_RES_WINREV: optional per-image factor of the GEMM branch (DropPath, model.py:986-987), hw = tokens per image
 };
 
 // dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.

@@ -143,7 +143,7 @@ extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int he
         bwd->wproj = at(pl.wp); bwd->wproj_t = at(pl.wp_t); bwd->bproj = raw->proj_b;
         bwd->w1 = at(pl.w1); bwd->w1_t = at(pl.w1_t); bwd->b1 = raw->lin1_b;
         bwd->wdw9 = (const float*)at(pl.w9); bwd->wdw9_flip = (const float*)at(pl.w9_flip); bwd->bdw = raw->dw_b;
-        bwd->w2_t = at(pl.w2_t);
+        bwd->w2_t = at(pl.w2_t); bwd->w2 = at(pl.w2);
         bwd->shift = shift; bwd->heads = heads;
     }
     return UF_OK;

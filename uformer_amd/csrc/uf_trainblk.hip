@@ -140,10 +140,8 @@ int recompute_attn(const uf_block_train_params* p, const BlockPlan& pl, const fl
     UF_TRY(uf_layernorm_fwd(x, C, p->norm1_w, p->norm1_b, p->modulator, pl.xn, B, H, W, C, 1, p->shift, dtype, st));
     UF_TRY(uf_qkv_fwd(pl.xn, p->wqkv, p->bqkv, pl.q, pl.k, pl.vt, M, C, p->heads, dtype, st));
     UF_TRY(uf_window_attention_fwd(pl.q, pl.k, pl.vt, p->rpb_dense, nullptr, 0, pl.o, M / 64, p->heads, 32, H, W, p->shift, dtype, st));
-    if (want_x1) {
-        UF_TRY(uf_linear_fwd(pl.o, p->wproj, p->bproj, pl.tA, M, C, C, 0, dtype, st));
-        UF_TRY(uf_residual_combine(x, pl.tA, 0, pl.x1, drop_attn, B, H, W, C, 1, p->shift, dtype, st));
-    }
+    if (want_x1)     // x1 = x + drop * window_reverse(proj(o)): residual, DropPath and un-partition in the projection GEMM's store
+        UF_TRY(uf_linear_residual_fwd(pl.o, p->wproj, p->bproj, x, pl.x1, drop_attn, B, H, W, C, C, 1, p->shift, dtype, st));
     return UF_OK;
 }
 

@@ -147,6 +147,25 @@ def linear(a: Tensor, w: Tensor, bias: Tensor, act: int = 0) -> Tensor:
     return out
 
 
+def linear_residual(a: Tensor, w: Tensor, bias: Tensor, resid: Tensor, scale: Optional[Tensor], B: int, H: int, W: int, windowed: bool = False,
+                    shift: int = 0) -> Tensor:
+    """resid + scale[image] * (a @ w.T + bias) as f32 (B*H*W, N) raster rows; ``a`` in window-row order when ``windowed`` (window_reverse and
+    the roll back happen in the store).  The projection / linear2 of a block with its residual add and DropPath (model.py:975-987)."""
+    _dev(a, w, bias, resid)
+    dt = uf_dtype(a.dtype)
+    a, w, resid = _c(a), _c(w, a.dtype), _c(resid, torch.float32)
+    M, K = a.shape
+    N = w.shape[0]
+    if M != B * H * W or resid.numel() != M * N:
+        raise UformerHipError(f"linear_residual: a {tuple(a.shape)} / resid {tuple(resid.shape)} do not match B*H*W = {B * H * W}, N = {N}")
+    sc = None if scale is None else _c(scale, torch.float32)
+    out = torch.empty((M, N), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().uf_linear_residual_fwd(_ptr(a), _ptr(w), _ptr(_c(bias, torch.float32)), _ptr(resid), _ptr(out), _ptr(sc) if sc is not None else None,
+                                                      B, H, W, N, K, int(windowed), shift, dt, _stream()), "uf_linear_residual_fwd")
+    return out
+
+
 def qkv(a: Tensor, wqkv: Tensor, bqkv: Tensor, heads: int):
     """LinearProjection.forward (model.py:431-442) -> q (scaled), k, v^T per (window, head)."""
     _dev(a, wqkv, bqkv)

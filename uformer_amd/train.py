@@ -83,6 +83,8 @@ class BlockPack:
             for k, v in keep.items():
                 setattr(tp, k, None if v is None else v.data_ptr())
             tp.shift, tp.heads = self.shift, self.heads
+            keep["w2"] = self.w2.contiguous()
+            tp.w2 = keep["w2"].data_ptr()
             self._train_params = tp
         return self._train_params
 
@@ -137,6 +139,21 @@ class NativeBlockPack:
         with torch.cuda.device(dev):
             _lib.check(lib.uf_pack_block_train(ctypes.byref(raw), C, heads, shift, dt, self._buf.data_ptr(), nbytes, ctypes.byref(self.fused),
                                                ctypes.byref(self.train_params), torch.cuda.current_stream().cuda_stream), "uf_pack_block_train")
+        # the same operands as tensors (views into the pack buffer) for the op-by-op forward / backward: the BlockPack attributes
+        tp, esz = self.train_params, torch.empty(0, dtype=T).element_size()
+
+        def view(ptr, shape, dtype=T, size=esz):
+            off, n = ptr - self._buf.data_ptr(), size
+            for d in shape:
+                n *= d
+            return self._buf[off:off + n].view(dtype).reshape(shape)
+
+        f32 = lambda ptr, shape: view(ptr, shape, torch.float32, 4)            # noqa: E731
+        self.wqkv, self.wqkv_t, self.bqkv = view(tp.wqkv, (3 * C, C)), view(tp.wqkv_t, (C, 3 * C)), f32(tp.bqkv, (3 * C,))
+        self.wp, self.wp_t = view(tp.wproj, (C, C)), view(tp.wproj_t, (C, C))
+        self.w1, self.w1_t, self.w2, self.w2_t = view(tp.w1, (4 * C, C)), view(tp.w1_t, (C, 4 * C)), view(tp.w2, (C, 4 * C)), view(tp.w2_t, (4 * C, C))
+        self.w9, self.w9_flip, self.bias = f32(tp.wdw9, (9, 4 * C)), f32(tp.wdw9_flip, (9, 4 * C)), f32(tp.rpb_dense, (heads, 64, 64))
+        self.mod = p[prefix + "modulator.weight"] if (prefix + "modulator.weight") in p else None
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -157,10 +174,10 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     xn = ops.layernorm(x2, f("norm1.weight"), f("norm1.bias"), B=B, H=H, W=W, dtype=T, windowed=True, shift=shift, modulator=pk.mod)
     q, k, vt = ops.qkv(xn, pk.wqkv, pk.bqkv, heads)                          # window rows; q already scaled
     o = ops.window_attention_core(q, k, vt, pk.bias, H=H, W=W, shift=shift)  # (M, C) window rows
-    yw = ops.linear(o, pk.wp, f("attn.proj.bias"))
     s1 = drop[0].float().contiguous() if drop is not None else None         # per-sample DropPath scales (B,)
     s2 = drop[1].float().contiguous() if drop is not None else None
-    x1 = ops.residual_combine(x2, yw, s1, B, H, W, windowed=True, shift=shift)     # x + DropPath(window_reverse(proj))   model.py:975-986
+    # x + DropPath(window_reverse(proj(o))): the residual add, the scale and the un-partition in the projection GEMM's store   model.py:975-986
+    x1 = ops.linear_residual(o, pk.wp, f("attn.proj.bias"), x2, s1, B, H, W, windowed=True, shift=shift)
     z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
     a1, h1 = ops.linear_pre_gelu(z, pk.w1, f("mlp.linear1.0.bias"))          # pre-activation (kept for GELU') and activation, one pass
     h1 = h1.reshape(B, H, W, 4 * C)
@@ -168,7 +185,7 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     g2 = g2.reshape(M, 4 * C)
     y = None
     if need_y:
-        y = ops.residual_combine(x1, ops.linear(g2, pk.w2, f("mlp.linear2.0.bias")), s2, B, H, W).reshape(B, L, C)
+        y = ops.linear_residual(g2, pk.w2, f("mlp.linear2.0.bias"), x1, s2, B, H, W).reshape(B, L, C)     # x1 + DropPath(linear2(.))   model.py:987
     saved = dict(s1=s1, s2=s2, p=p, prefix=prefix, heads=heads, shift=shift, T=T, shape=(B, L, C), x2=x2, xn=xn, q=q, k=k, vt=vt, o=o, x1=x1, z=z, a1=a1,
                  h1=h1, c=c, g2=g2, pk=pk, mod=pk.mod is not None)
     return y, saved
@@ -368,7 +385,8 @@ class UformerTape:
                 # the fused kernels (and the block-level C backward built on them) cover head_dim 32; a head_dim-16 block (Uformer_T,
                 # utils/model_utils.py:66-67) takes the op-by-op forward that keeps its intermediates and the op-level backward
                 fusable = self.recompute and C == 32 * cfg.num_heads[s]
-                native = fusable and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
+                # uf_pack_block_train (5 launches) covers C % 32 == 0; its pack also serves the op-by-op form as tensor views
+                native = C % 32 == 0 and C % cfg.num_heads[s] == 0 and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
                 pk = self.packs[prefix] = (NativeBlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T) if native else
                                            BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=fusable))
                 if fusable:                                                     # fused kernels; the block's input is all that is kept
