@@ -55,6 +55,27 @@ def main():
                 tot["wgrad"] = tot.get("wgrad", 0) + us
                 print(f"wgrad_{nm:5s}        {tag:14s} {us:9.1f} us  {2.0 * M * N * K / us / 1e6:7.1f} TFLOP/s  {(M * (N + K) * 2) / us / 1e3:7.0f} GB/s")
                 del dy, x
+        if what in ("gemm", "all"):
+            # the GEMMs of one block in the op-by-op training step: forward linear1 (two outputs), input gradients dc (times GELU'), dz, dO, dxn
+            z = torch.randn(M, C, device="cuda").to(T)
+            a4 = torch.randn(M, C4, device="cuda").to(T)
+            q3 = torch.randn(M, 3 * C, device="cuda").to(T)
+            w1, w1t = (torch.randn(C4, C, device="cuda") / C ** 0.5).to(T), (torch.randn(C, C4, device="cuda") / C ** 0.5).to(T)
+            wq, wqt = (torch.randn(3 * C, C, device="cuda") / C ** 0.5).to(T), (torch.randn(C, 3 * C, device="cuda") / C ** 0.5).to(T)
+            wp = (torch.randn(C, C, device="cuda") / C ** 0.5).to(T)
+            b4, b1, zero4, zero1 = torch.randn(C4, device="cuda"), torch.randn(C, device="cuda"), torch.zeros(C4, device="cuda"), torch.zeros(C, device="cuda")
+            x32 = torch.randn(M, C, device="cuda")
+            for name, fn, n, k, by in (("fc1_pre_gelu", lambda: ops.linear_pre_gelu(z, w1, b4), C4, C, M * (C + 2 * C4) * 2),
+                                       ("dc_mul_dgelu", lambda: ops.linear_mul_dgelu(z, w1, zero4, a4), C4, C, M * (C + 2 * C4) * 2),
+                                       ("dz (N=C,K=4C)", lambda: ops.linear(a4, w1t, zero1), C, C4, M * (C4 + C) * 2),
+                                       ("fc2_residual", lambda: ops.linear_residual(a4, w1t, b1, x32, None, B, H, H), C, C4, M * (C4 * 2 + C * 8)),
+                                       ("dxn (N=C,K=3C)", lambda: ops.linear(q3, wqt, zero1), C, 3 * C, M * (3 * C + C) * 2),
+                                       ("dO (N=C,K=C)", lambda: ops.linear(z, wp, zero1), C, C, M * 2 * C * 2),
+                                       ("qkv", lambda: ops.qkv(z, wq, torch.zeros(3 * C, device="cuda"), heads), 3 * C, C, M * 4 * C * 2)):
+                us = timeit(fn)
+                tot["gemm"] = tot.get("gemm", 0) + us
+                print(f"gemm {name:14s} {tag:14s} {us:9.1f} us  {2.0 * M * n * k / us / 1e6:7.1f} TFLOP/s  {by / us / 1e3:7.0f} GB/s")
+            del z, a4, q3, x32
         if what in ("attn", "all"):
             nW, hd = M // 64, 32
             q = (torch.randn(nW, heads, 64, hd, device="cuda") * hd ** -0.5).to(T)

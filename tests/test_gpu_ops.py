@@ -145,6 +145,37 @@ def test_linear(ops, dtype, M, N, K, act):
     check(f"linear_{M}x{N}x{K}_act{act}", got, ref, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(16384, 1024, 256), (32768, 512, 1024)])
+def test_gemm_training_shapes(ops, dtype, M, N, K):
+    """Stage-sized products (thousands of 128 x 128 tiles, several K tiles) through every epilogue the training step uses: plain store,
+    GELU, pre-activation + GELU, times GELU', and the residual stores (plain and window_reverse with DropPath scales)."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=gen) + torch.arange(M)[:, None] * 1e-5).to(dtype)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dtype)
+    b = torch.randn(N, generator=gen)
+    ref = a.float() @ w.float().t() + b
+    ac, wc, bc = a.cuda(), w.cuda(), b.cuda()
+    check(f"big_linear_{M}x{N}x{K}", ops.linear(ac, wc, bc), ref, dtype)
+    check(f"big_linear_gelu_{M}x{N}x{K}", ops.linear(ac, wc, bc, 1), O.gelu_erf(ref), dtype)
+    pre, act = ops.linear_pre_gelu(ac, wc, bc)
+    check(f"big_pre_{M}x{N}x{K}", pre, ref, dtype)
+    assert torch.equal(act, ops.gelu(pre))                                         # GELU of the value as stored
+    prev = torch.randn(M, N, generator=gen).to(dtype).cuda()
+    got = ops.linear_mul_dgelu(ac, wc, bc, prev)
+    check(f"big_mul_dgelu_{M}x{N}x{K}", got, ops.gelu_bwd(prev, ops.linear(ac, wc, bc)).float().cpu(), dtype)   # the two-pass form on the same rounded product
+    B, H, W = M // 4096, 64, 64
+    x = torch.randn(M, N, generator=gen)
+    sc = 1.25 * (torch.arange(B) % 3 != 0).float()
+    srow = sc.repeat_interleave(H * W).reshape(M, 1)
+    tol = 2e-6
+    out = ops.linear_residual(ac, wc, bc, x.cuda(), sc.cuda(), B, H, W).cpu()
+    assert ((out - (x + srow * ref)).abs().max() / (x + srow * ref).abs().max()).item() < tol
+    outw = ops.linear_residual(ac, wc, bc, x.cuda(), sc.cuda(), B, H, W, windowed=True, shift=4).cpu()
+    refw = x + srow * ops.window_reverse(ref.reshape(-1, 8, 8, N).cuda(), 8, H, W, 4).reshape(M, N).cpu()
+    assert ((outw - refw).abs().max() / refw.abs().max()).item() < tol
+
+
 @pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (64, 2), (128, 4), (256, 8), (512, 16)])
 def test_ln_fused_projections(ops, dtype, C, heads):
