@@ -311,6 +311,48 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 }
             }
         }
+    } else if constexpr (EP == E_RES || EP == E_RES_WINREV) {
+        // f32 residual outputs: the wave's tile goes through LDS as f32 and leaves row by row, so the residual loads and the stores are
+        // whole 128-256 byte runs of the token rows (as 16 bytes per lane at 16 different rows they were 64-byte pieces: the residual
+        // forms of the projection / linear2 GEMMs cost 3.4 ms more per training step than the same products with a plain store)
+        constexpr int WTM = TM * 16, WTN = TN * 16;
+        constexpr int SROWF = WTN * 4 + 16;
+        constexpr int STGF = WTM * SROWF;
+        static_assert(4 * STGF <= 2 * BUF_BYTES, "f32 staging does not fit the main-loop LDS");
+        char* stg = smem + wave * STGF;
+        const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const f32x4 b = epilogue_bias<EP>(p, nw0 + i * 16 + fg * 4);
+#pragma unroll
+            for (int j = 0; j < TM; ++j) *reinterpret_cast<f32x4*>(stg + (j * 16 + fr) * SROWF + (i * 16 + fg * 4) * 4) = acc[i][j] + b;
+        }
+        constexpr int CPR = WTN / 4, RPI = 64 / CPR, NIT = WTM / RPI;     // 16-byte chunks per row, rows per pass
+        const int r0 = lane / CPR, cb = lane % CPR;
+        const int n = nw0 + cb * 4;
+        const bool nok = n < p.N;
+        const int ncl = nok ? n : p.N - 4;
+        // token rows, residual values and DropPath factors of every pass requested up front, from clamped addresses
+        int tok[NIT];
+        f32x4 res[NIT];
+        float sc[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = mw0 + it * RPI + r0;
+            const int mc = m < p.M ? m : p.M - 1;
+            tok[it] = EP == E_RES_WINREV ? window_row_to_token(mc, p.H, p.W_, p.shift) : mc;
+            res[it] = *reinterpret_cast<const f32x4*>(p.resid + (size_t)tok[it] * p.ldr + ncl);
+            sc[it] = p.scale ? p.scale[tok[it] / p.hw] : 1.0f;   // training: x + DropPath(branch), bernoulli(keep) / keep per sample
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI + r0;
+            if (mw0 + r < p.M && nok) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * SROWF + cb * 16);
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)tok[it] * p.ldo + n) = res[it] + v * sc[it];
+            }
+        }
     } else {
         f32x4 bv[TN];
 #pragma unroll
@@ -336,10 +378,10 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     // K within ONE tile (K <= 64 for the 2-byte types: every projection of the 32- and 64-channel stages, the ones with the most tokens):
     // the second LDS buffer is never touched, and without it 3-4 workgroups fit a CU instead of 2 -- these launches are streams of
     // short load -> MFMA -> store chains, bound by how many of them are in flight.  (The staged epilogue of the 2-byte types fits one
-    // buffer; the f32 one does not.)  UF_GEMM_LDS2=1 keeps both buffers, for A/B runs.
+    // buffer; the f32 one and the f32 staging of the residual stores do not.)  UF_GEMM_LDS2=1 keeps both buffers, for A/B runs.
     static const bool lds2 = getenv("UF_GEMM_LDS2") != nullptr;
     constexpr int BKE = 8 * (16 / (int)sizeof(T));
-    const int smem = (sizeof(T) == 2 && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;
+    const int smem = (sizeof(T) == 2 && EP != E_RES && EP != E_RES_WINREV && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;   // (the f32 staging of the residual stores needs both)
     const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";
