@@ -20,7 +20,8 @@ python $R/scripts/rocprof_summary.py /tmp/kt16/kt16_results.db $O/r03_final_f16 
 unset UF_STREAMS
 rocprofv3 --kernel-trace --stats -d /tmp/ktt -o ktt -- python $R/scripts/train_bench.py --batch 32 --steps 2 --warmup 1 > $O/ktt.log 2>&1
 python $R/scripts/rocprof_summary.py /tmp/ktt/ktt_results.db $O/r03_train_final | tail -2
-(cd $R && for d in bf16 f16; do python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 --dtype $d 2>/dev/null | tail -1; done) | tee $O/r03_train_step.json
+(cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 --dtype bf16 --kernels-json $O/r03_train_kernels_hip_events.json 2>/dev/null | tail -1;
+ cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 --dtype f16 2>/dev/null | tail -1) | tee $O/r03_train_step.json
 (cd $R && bash scripts/run_sweep.sh 2>/dev/null | tail -12)
 (cd $R && python bench.py --img 1280 --batch 1 --steps 10 --warmup 3 --no-cpu-baseline --no-f32-mode --no-train-mode 2>/dev/null | cut -c1-600) | tee $O/r03_bench_720p.json
 (cd $R && python bench.py --error-budget --kernels-json $O/r03_kernels_hip_events.json > $O/r03_bench.json 2> $O/bench.err; cut -c1-900 $O/r03_bench.json)
