@@ -42,6 +42,7 @@ def main():
             nbytes = h.numel() * 2
             for name, fn, passes in (("dwconv_plain", lambda: ops.dwconv3x3(h, w9, bias, gelu=False), 2), ("dwconv_pre_gelu", lambda: ops.dwconv3x3_pre_gelu(h, w9, bias), 3),
                                      ("dwconv_mul_dgelu", lambda: ops.dwconv3x3_mul_dgelu(h, w9, a), 3), ("dwconv_wgrad", lambda: ops.dwconv3x3_wgrad(h, a), 2),
+                                     ("dwconv_bwd_fused", lambda: ops.dwconv3x3_bwd(h, w9, a), 3),
                                      ("gelu_fwd", lambda: ops.gelu(h), 2)):
                 us = timeit(fn)
                 tot[name] = tot.get(name, 0) + us

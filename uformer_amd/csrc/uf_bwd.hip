@@ -312,25 +312,6 @@ __global__ __launch_bounds__(256) void dwconv3x3_wgrad_finalize(const float* __r
 // of a channel group meet in LDS (fixed order) and ONE partial per workgroup and channel goes to the workspace;
 // dwconv3x3_bwd_finalize adds the workgroups in order.  Bit-reproducible, no atomics.
 // ---------------------------------------------------------------------------------------------------------------
-// N channels of the operand type as one load / store: 16 bytes (8 x 2-byte, 4 x f32) or 8 bytes (4 x 2-byte)
-template <typename T, int N> struct Chunk;
-template <typename T> struct Chunk<T, 8> {
-    static_assert(sizeof(T) == 2, "8 channels of a 2-byte type");
-    using Raw = u32x4;
-    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { unpack8<T>(r, f); }
-    static __device__ __forceinline__ Raw pack(const float* f) { return pack8<T>(f); }
-};
-template <typename T> struct Chunk<T, 4> {
-    using Raw = typename std::conditional<sizeof(T) == 2, u32x2, u32x4>::type;
-    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
-        if constexpr (sizeof(T) == 2) { unpack2<T>(r[0], f[0], f[1]); unpack2<T>(r[1], f[2], f[3]); }
-        else { f[0] = __uint_as_float(r[0]); f[1] = __uint_as_float(r[1]); f[2] = __uint_as_float(r[2]); f[3] = __uint_as_float(r[3]); }
-    }
-    static __device__ __forceinline__ Raw pack(const float* f) {
-        if constexpr (sizeof(T) == 2) return Raw{pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3])};
-        else return Raw{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
-    }
-};
 template <typename T, int N> __device__ __forceinline__ void round_t(float* f) {   // to the operand type and back (what a later pass would read)
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -455,6 +436,141 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_kernel(const T* __restri
         }
     }
     // the pixel threads of a channel group meet in LDS: thread (cgi, i) adds its px partners in pixel order
+    float* out = partial + (size_t)blockIdx.x * 10 * cg * N;
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[tid][i] = wacc[t][i];
+        __syncthreads();
+        if (tid < cg * N) {
+            const int g = tid / N, i = tid % N;
+            float s = 0.f;
+            for (int q = 0; q < px; ++q) s += red[q * cg + g][i];
+            out[t * cg * N + tid] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// The same pass WALKING along x (W a multiple of 8): a thread owns 4 channels x a strip of R rows x SEG consecutive pixel columns per
+// position step and keeps the last three dc columns ((R + 2) rows each) in registers as f32 -- one new column per step instead of
+// three -- exactly as dwconv3x3_walk_kernel does for the forward (uf_elementwise.hip: the 3x re-read of the input through L1 / L2 was
+// what held the one-column-per-thread form at 2.8 TB/s).  Positions are (image, strip, segment); same partial-sum layout.
+template <typename T, int SEG>
+__global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_walk_kernel(const T* __restrict__ dc, const float* __restrict__ w9f, const T* __restrict__ a1,
+                                                                    T* __restrict__ da1, float* __restrict__ partial, int B, int H, int W, int C, int cg_log2) {
+    constexpr int N = 4, R = DWB_R;
+    using CH = Chunk<T, N>;
+    using Raw = typename CH::Raw;
+    __shared__ float red[256][N + 1];
+    const int tid = threadIdx.x;
+    const int cg = 1 << cg_log2, cv = C / N, cb = cv >> cg_log2, px = 256 >> cg_log2;
+    const int cgi = tid & (cg - 1), pi = tid >> cg_log2;
+    const int c = (((int)blockIdx.x % cb) * cg + cgi) * N;
+    const int strips = H / R, segs = W / SEG;
+    const int P = B * strips * segs;
+    const int pstep = ((int)gridDim.x / cb) * px;
+    const unsigned pixb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * pixb;
+    const char* dcb = reinterpret_cast<const char*>(dc);
+    const char* a1b = reinterpret_cast<const char*>(a1);
+    char* dab = reinterpret_cast<char*>(da1);
+    f32x4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(w9f + (size_t)t * C + c);
+    float wacc[10][N];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int i = 0; i < N; ++i) wacc[t][i] = 0.f;
+    for (int pos = ((int)blockIdx.x / cb) * px + pi; pos < P; pos += pstep) {
+        const int x0 = (pos % segs) * SEG, rest = pos / segs;
+        const int y0 = (rest % strips) * R, b = rest / strips;
+        const unsigned o00 = ((unsigned)(b * H + y0) * W + x0) * pixb + (unsigned)c * (unsigned)sizeof(T);
+        unsigned ro[R + 2];
+        ro[0] = y0 > 0 ? o00 - rowb : o00;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ro[r + 1] = o00 + r * rowb;
+        ro[R + 1] = y0 + R < H ? o00 + R * rowb : o00 + (R - 1) * rowb;
+        const float mtop = y0 > 0 ? 1.0f : 0.0f, mbot = y0 + R < H ? 1.0f : 0.0f;
+        float col[3][R + 2][N];        // dc columns xx - 1, xx, xx + 1 of the current pixel column xx, rotating
+        auto load_col = [&](float (&cl)[R + 2][N], int dx, float m) {
+            Raw raw[R + 2];
+#pragma unroll
+            for (int r = 0; r < R + 2; ++r) raw[r] = *reinterpret_cast<const Raw*>(dcb + (ro[r] + (unsigned)(dx * (int)pixb)));
+#pragma unroll
+            for (int r = 0; r < R + 2; ++r) {
+                CH::unpack(raw[r], cl[r]);
+                const float mr = (r == 0 ? mtop : (r == R + 1 ? mbot : 1.0f)) * m;
+                if (r == 0 || r == R + 1) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) cl[r][i] *= mr;
+                } else if (m != 1.0f) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) cl[r][i] *= m;
+                }
+            }
+        };
+        auto emit = [&](const float (&cL)[R + 2][N], const float (&cM)[R + 2][N], const float (&cR)[R + 2][N], int dx) {
+            Raw araw[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) araw[r] = *reinterpret_cast<const Raw*>(a1b + (ro[r + 1] + (unsigned)(dx * (int)pixb)));
+            float hc[R][N], acc[R][N];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                CH::unpack(araw[r], hc[r]);
+                gelu_n<T, N>(hc[r]);
+                round_t<T, N>(hc[r]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { acc[r][i] = 0.f; wacc[9][i] += cM[r + 1][i]; }
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float (&cl)[R + 2][N] = kx == 0 ? cL : (kx == 1 ? cM : cR);
+#pragma unroll
+                for (int r = -1; r <= R; ++r)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int orow = r + 1 - ky;
+                        if (orow < 0 || orow >= R) continue;
+#pragma unroll
+                        for (int i = 0; i < N; ++i) {
+                            acc[orow][i] = fmaf(cl[r + 1][i], wt[ky * 3 + kx][i], acc[orow][i]);
+                            wacc[(2 - ky) * 3 + (2 - kx)][i] = fmaf(hc[orow][i], cl[r + 1][i], wacc[(2 - ky) * 3 + (2 - kx)][i]);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float a[N];
+                CH::unpack(araw[r], a);
+                round_t<T, N>(acc[r]);
+#pragma unroll
+                for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
+                *reinterpret_cast<Raw*>(dab + (ro[r + 1] + (unsigned)(dx * (int)pixb))) = CH::pack(acc[r]);
+            }
+        };
+        load_col(col[0], x0 > 0 ? -1 : 0, x0 > 0 ? 1.0f : 0.0f);
+        load_col(col[1], 0, 1.0f);
+        const bool last_seg = x0 + SEG >= W;
+#pragma unroll 1
+        for (int xs = 0; xs < SEG; xs += 3) {          // three steps per turn: the column registers rotate by name
+            {
+                const bool edge = last_seg && xs + 1 >= SEG;
+                load_col(col[2], edge ? xs : xs + 1, edge ? 0.0f : 1.0f);
+                emit(col[0], col[1], col[2], xs);
+            }
+            if (xs + 1 < SEG) {
+                const bool edge = last_seg && xs + 2 >= SEG;
+                load_col(col[0], edge ? xs + 1 : xs + 2, edge ? 0.0f : 1.0f);
+                emit(col[1], col[2], col[0], xs + 1);
+            }
+            if (xs + 2 < SEG) {
+                const bool edge = last_seg && xs + 3 >= SEG;
+                load_col(col[1], edge ? xs + 2 : xs + 3, edge ? 0.0f : 1.0f);
+                emit(col[2], col[0], col[1], xs + 2);
+            }
+        }
+    }
     float* out = partial + (size_t)blockIdx.x * 10 * cg * N;
 #pragma unroll
     for (int t = 0; t < 10; ++t) {
@@ -1072,24 +1188,23 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
     return check_launch("dwconv3x3_wgrad_finalize");
 }
 
-// geometry of dwconv3x3_bwd_kernel for C channels: N channels per thread (2-byte operands: 4 = 8-byte loads at ~120 VGPRs, the default,
-// or 8 with UF_DWBWD_VEC=8 = 16-byte loads at the register limit; f32: 4), channel groups per workgroup (a power of two dividing C / N,
-// at most 32), workgroups (UF_DWBWD_BLOCKS, default 1024 = four per CU, rounded up to whole channel-block rounds)
-static void dw_bwd_geometry(int C, uf_dtype dtype, int* cg_log2, int* blocks, int* N_) {
+// geometry of the fused depthwise backward for C channels: 4 channels per thread (8-byte loads for the 2-byte types; with 8 the
+// accumulators spill), channel groups per workgroup (a power of two dividing C / 4, at most 32), workgroups (UF_DWBWD_BLOCKS,
+// default 1024 = four per CU, rounded up to whole channel-block rounds)
+static void dw_bwd_geometry(int C, int* cg_log2, int* blocks) {
     static const int target = getenv("UF_DWBWD_BLOCKS") ? atoi(getenv("UF_DWBWD_BLOCKS")) : 0;
-    static const int vec8 = getenv("UF_DWBWD_VEC") ? atoi(getenv("UF_DWBWD_VEC")) == 8 : 0;
-    const int N = (dtype_half(dtype) && vec8 && C % 8 == 0) ? 8 : 4, cv = C / N;
+    const int cv = C / 4;
     int lg = 0;
     while (lg < 5 && cv % (2 << lg) == 0) ++lg;
-    const int cb = cv >> lg, want = target > 0 ? target : (N == 8 ? 512 : 1024);
-    *cg_log2 = lg; *blocks = (want + cb - 1) / cb * cb; *N_ = N;
+    const int cb = cv >> lg, want = target > 0 ? target : 1024;
+    *cg_log2 = lg; *blocks = (want + cb - 1) / cb * cb;
 }
 
 extern "C" size_t uf_dwconv3x3_bwd_workspace_bytes(int C, uf_dtype dtype) {
     if (C <= 0 || !dtype_ok(dtype) || C % (dtype_half(dtype) ? 8 : 4)) return 0;
-    int lg, blocks, N;
-    dw_bwd_geometry(C, dtype, &lg, &blocks, &N);
-    return (size_t)blocks * 10 * (N << lg) * sizeof(float);
+    int lg, blocks;
+    dw_bwd_geometry(C, &lg, &blocks);
+    return (size_t)blocks * 10 * (4 << lg) * sizeof(float);
 }
 
 extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const void* pre, void* da, float* dw9, float* dbias, int B, int H, int W, int C,
@@ -1104,22 +1219,30 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
                "uf_dwconv3x3_bwd: operands must be 16-byte aligned");
     const size_t need = uf_dwconv3x3_bwd_workspace_bytes(C, dtype);
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_dwconv3x3_bwd: workspace too small: %zu < %zu", ws_bytes, need);
-    int lg, blocks, N;
-    dw_bwd_geometry(C, dtype, &lg, &blocks, &N);
-    const int cb = (C / N) >> lg;
+    int lg, blocks;
+    dw_bwd_geometry(C, &lg, &blocks);
+    const int cb = (C / 4) >> lg;
     hipStream_t st = (hipStream_t)stream;
-    static const bool rows2 = getenv("UF_DWBWD_ROWS") && atoi(getenv("UF_DWBWD_ROWS")) == 2;   // A/B (bf16): strips of 2 rows
+    static const bool walk = !(getenv("UF_DWCONV_WALK") && atoi(getenv("UF_DWCONV_WALK")) == 0);   // 0: one pixel column per thread (A/B)
+    // the walking form for the 2-byte types (with f32 operands its 72 column registers on top of the erf-form GELU spill)
+    const int seg = (walk && dtype_half(dtype) && W % 8 == 0) ? (W % 16 == 0 ? 16 : 8) : 0;
 #define UF_DWBWD_ARGS dim3(blocks), dim3(256), 0, st, (const TT*)dc, w9_flipped, (const TT*)pre, (TT*)da, (float*)ws, B, H, W, C, lg
     if (dtype == UF_F32) { using TT = float; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
-    else if (dtype == UF_BF16 && N == 4 && rows2) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, 2>), UF_DWBWD_ARGS); }
-    else if (dtype == UF_BF16 && N == 4) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
-    else if (dtype == UF_BF16) { using TT = bf16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 8, DWB_R>), UF_DWBWD_ARGS); }
-    else if (N == 4) { using TT = f16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
-    else { using TT = f16; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 8, DWB_R>), UF_DWBWD_ARGS); }
+    else if (dtype == UF_BF16) {
+        using TT = bf16;
+        if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
+        else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
+        else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
+    } else {
+        using TT = f16;
+        if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
+        else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
+        else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
+    }
 #undef UF_DWBWD_ARGS
     int rc = check_launch("dwconv3x3_bwd");
     if (rc) return rc;
-    hipLaunchKernelGGL(dwconv3x3_bwd_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks, cb, N << lg, dw9, dbias, C);
+    hipLaunchKernelGGL(dwconv3x3_bwd_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks, cb, 4 << lg, dw9, dbias, C);
     return check_launch("dwconv3x3_bwd_finalize");
 }
 

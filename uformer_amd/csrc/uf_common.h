@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/uformer_hip.h"
 
@@ -154,6 +155,26 @@ template <typename T> __device__ __forceinline__ void gelu4(f32x4& v) {
     gelu_n<T, 4>(t);
     v = f32x4{t[0], t[1], t[2], t[3]};
 }
+
+// N channels of the operand type as one load / store: 16 bytes (8 x 2-byte, 4 x f32) or 8 bytes (4 x 2-byte)
+template <typename T, int N> struct Chunk;
+template <typename T> struct Chunk<T, 8> {
+    static_assert(sizeof(T) == 2, "8 channels of a 2-byte type");
+    using Raw = u32x4;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) { unpack8<T>(r, f); }
+    static __device__ __forceinline__ Raw pack(const float* f) { return pack8<T>(f); }
+};
+template <typename T> struct Chunk<T, 4> {
+    using Raw = typename std::conditional<sizeof(T) == 2, u32x2, u32x4>::type;
+    static __device__ __forceinline__ void unpack(const Raw& r, float* f) {
+        if constexpr (sizeof(T) == 2) { unpack2<T>(r[0], f[0], f[1]); unpack2<T>(r[1], f[2], f[3]); }
+        else { f[0] = __uint_as_float(r[0]); f[1] = __uint_as_float(r[1]); f[2] = __uint_as_float(r[2]); f[3] = __uint_as_float(r[3]); }
+    }
+    static __device__ __forceinline__ Raw pack(const float* f) {
+        if constexpr (sizeof(T) == 2) return Raw{pack2<T>(f[0], f[1]), pack2<T>(f[2], f[3])};
+        else return Raw{__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+    }
+};
 
 // ------------------------------------------------------------------------------------
 // debug census (uf_debug_set_tbuf): every workgroup records where and when it ran, so the host can count how many

@@ -200,6 +200,114 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
     }
 }
 
+// The same stencil (ACT 0, 1, 2) WALKING along x.  The kernel above gives a thread one pixel column: each input vector is then requested
+// by the threads of three neighbouring columns, i.e. three different waves, and with the one-tap timing ablation (profiles/
+// r03_kx_abl.txt) it ran at 5.3-5.9 TB/s against 3.4-3.9 TB/s: the 3x re-read through L1 / L2 was the limit, not HBM.  Here a thread
+// owns 4 channels x a strip of DW_R rows x SEG consecutive pixel columns and keeps the last three input columns ((DW_R + 2) rows
+// each) in registers as f32: every step loads ONE new column (6 x 8 bytes for the 2-byte types), so an input element is loaded
+// (SEG + 2) / SEG x 1.5 times instead of 4.5.  4 channels, not 8: 72 column + 36 tap + 16 accumulator registers leave 4 waves / SIMD.
+// Same FMA order per output as the kernel above (column taps outermost, then rows): bit-identical results.
+template <typename T, int ACT, int SEG>
+__global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict__ x, const float* __restrict__ w9, const float* __restrict__ bias,
+                                                             T* __restrict__ out, T* __restrict__ aux, int B, int H, int W, int C) {
+    constexpr int N = 4, R = DW_R;
+    using CH = Chunk<T, N>;
+    using Raw = typename CH::Raw;
+    const int cv = C / N, strips = H / R, segs = W / SEG;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)B * strips * segs * cv) return;
+    const int c = (int)(idx % cv) * N;
+    long long rest = idx / cv;
+    const int x0 = (int)(rest % segs) * SEG; rest /= segs;
+    const int y0 = (int)(rest % strips) * R;
+    const int b = (int)(rest / strips);
+    f32x4 wt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(w9 + (size_t)t * C + c);
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // 32-bit byte offsets from the tensor base (the launcher checks the tensor is under 4 GiB); halo rows clamped into the image, masked
+    const unsigned pixb = (unsigned)C * (unsigned)sizeof(T), rowb = (unsigned)W * pixb;
+    const unsigned o00 = ((unsigned)(b * H + y0) * W + x0) * pixb + (unsigned)c * (unsigned)sizeof(T);
+    unsigned ro[R + 2];
+    ro[0] = y0 > 0 ? o00 - rowb : o00;
+#pragma unroll
+    for (int r = 0; r < R; ++r) ro[r + 1] = o00 + r * rowb;
+    ro[R + 1] = y0 + R < H ? o00 + R * rowb : o00 + (R - 1) * rowb;
+    const float mtop = y0 > 0 ? 1.0f : 0.0f, mbot = y0 + R < H ? 1.0f : 0.0f;
+    const char* xb = reinterpret_cast<const char*>(x);
+    char* ob = reinterpret_cast<char*>(out);
+    char* ab = reinterpret_cast<char*>(aux);
+
+    float col[3][R + 2][N];        // input columns xx - 1, xx, xx + 1 of the current output column xx, rotating
+    auto load_col = [&](float (&cl)[R + 2][N], int dx, float m) {      // column x0 + dx (clamped by the caller), times the column mask m
+        Raw raw[R + 2];
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) raw[r] = *reinterpret_cast<const Raw*>(xb + (ro[r] + (unsigned)(dx * (int)pixb)));
+#pragma unroll
+        for (int r = 0; r < R + 2; ++r) {
+            CH::unpack(raw[r], cl[r]);
+            const float mr = (r == 0 ? mtop : (r == R + 1 ? mbot : 1.0f)) * m;
+            if (r == 0 || r == R + 1) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) cl[r][i] *= mr;
+            } else if (m != 1.0f) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) cl[r][i] *= m;
+            }
+        }
+    };
+    auto emit = [&](const float (&cL)[R + 2][N], const float (&cM)[R + 2][N], const float (&cR)[R + 2][N], int dx) {
+        float acc[R][N];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { acc[r][0] = bv[0]; acc[r][1] = bv[1]; acc[r][2] = bv[2]; acc[r][3] = bv[3]; }
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float (&cl)[R + 2][N] = kx == 0 ? cL : (kx == 1 ? cM : cR);
+#pragma unroll
+            for (int r = -1; r <= R; ++r)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = r + 1 - ky;
+                    if (orow < 0 || orow >= R) continue;
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[orow][i] = fmaf(cl[r + 1][i], wt[ky * 3 + kx][i], acc[orow][i]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned o = ro[r + 1] + (unsigned)(dx * (int)pixb);
+            if constexpr (ACT == 1) gelu_n<T, N>(acc[r]);
+            *reinterpret_cast<Raw*>(ob + o) = CH::pack(acc[r]);
+            if constexpr (ACT == 2) {
+                round_to<T, N>(acc[r]);
+                gelu_n<T, N>(acc[r]);
+                *reinterpret_cast<Raw*>(ab + o) = CH::pack(acc[r]);
+            }
+        }
+    };
+    load_col(col[0], x0 > 0 ? -1 : 0, x0 > 0 ? 1.0f : 0.0f);
+    load_col(col[1], 0, 1.0f);
+    const bool last_seg = x0 + SEG >= W;
+#pragma unroll 1
+    for (int xs = 0; xs < SEG; xs += 3) {          // three steps per turn: the column registers rotate by name
+        {
+            const bool edge = last_seg && xs + 1 >= SEG;
+            load_col(col[2], edge ? xs : xs + 1, edge ? 0.0f : 1.0f);
+            emit(col[0], col[1], col[2], xs);
+        }
+        if (xs + 1 < SEG) {
+            const bool edge = last_seg && xs + 2 >= SEG;
+            load_col(col[0], edge ? xs + 1 : xs + 2, edge ? 0.0f : 1.0f);
+            emit(col[1], col[2], col[0], xs + 1);
+        }
+        if (xs + 2 < SEG) {
+            const bool edge = last_seg && xs + 3 >= SEG;
+            load_col(col[1], edge ? xs + 2 : xs + 3, edge ? 0.0f : 1.0f);
+            emit(col[2], col[0], col[1], xs + 2);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // a12: InputProj conv3x3(Cin->E) + LeakyReLU(0.01), NCHW image -> token rows (model.py:853-866).
 // A thread owns 4 output channels x IP_PX horizontally adjacent pixels: the 27 weight vectors are loaded
@@ -452,6 +560,17 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
 namespace {
 template <typename T, int ACT>
 void launch_dwconv(const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, hipStream_t st) {
+    if constexpr (ACT != 3) {     // the walking form: W a multiple of 8, tensor under 4 GiB (32-bit byte offsets); UF_DWCONV_WALK=0 turns it off (A/B)
+        static const bool walk = !(getenv("UF_DWCONV_WALK") && atoi(getenv("UF_DWCONV_WALK")) == 0);
+        if (walk && W % 8 == 0 && C % 4 == 0 && (unsigned long long)B * H * W * C * sizeof(T) < 0xffffffffULL) {
+            const int seg = W % 16 == 0 ? 16 : 8;
+            const long long n = (long long)B * (H / DW_R) * (W / seg) * (C / 4);
+            const dim3 grid((unsigned)((n + 255) / 256));
+            if (seg == 16) hipLaunchKernelGGL((dwconv3x3_walk_kernel<T, ACT, 16>), grid, dim3(256), 0, st, (const T*)x, w9, bias, (T*)out, (T*)aux, B, H, W, C);
+            else hipLaunchKernelGGL((dwconv3x3_walk_kernel<T, ACT, 8>), grid, dim3(256), 0, st, (const T*)x, w9, bias, (T*)out, (T*)aux, B, H, W, C);
+            return;
+        }
+    }
     constexpr int N = Vec16<T>::N;
     const long long n = (long long)B * (H / DW_R) * W * (C / N);
     hipLaunchKernelGGL((dwconv3x3_gelu_kernel<T, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const T*)x, w9, bias, (T*)out, (T*)aux, B, H, W, C);

@@ -362,12 +362,12 @@ class UformerTape:
         self.B, self.H = B, H
         if self.recompute is None:
             # Keeping every intermediate of the op-by-op forward costs ~60 bytes per token x channel of every block (measured: 56 GB for
-            # Uformer-B 256^2 at batch 32 against 17 GB) and saves the recomputation in the backward: 332 vs 314 img/s on an MI355X
-            # (profiles/r03_recompute_ab.txt).  288 GB of HBM is there to be used: keep them while that is under half of the free memory.
+            # Uformer-B 256^2 at batch 32 against 17 GB) and saves the recomputation in the backward: 371 vs 334 img/s on an MI355X
+            # (profiles/r03_host.txt).  288 GB of HBM is there to be used: keep them while that is under half of the free memory.
             dims, div = cfg.stage_dims(), cfg.stage_res_div()
             need = 60 * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
             free = torch.cuda.mem_get_info(img.device)[0]
-            self.recompute = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 327 vs 330 img/s): keep the small one
+            self.recompute = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 356 vs 357 img/s): keep the small one
         shifts = cfg.block_shifts()
         res = self.res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
         first = [sum(cfg.depths[:s]) for s in range(9)]
