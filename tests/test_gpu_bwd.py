@@ -447,7 +447,8 @@ def test_backward_streaming_helpers(dtype, shift):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,nchw", [(2, 24, 40, 3, 32, True), (1, 16, 16, 3, 16, True), (3, 8, 20, 4, 32, True), (1, 8, 12, 3, 64, True),
-                                                  (2, 24, 40, 64, 3, False), (1, 16, 16, 32, 3, False), (5, 300, 12, 8, 4, False)])
+                                                  (2, 24, 40, 64, 3, False), (1, 16, 16, 32, 3, False), (5, 300, 12, 8, 4, False), (2, 12, 48, 64, 3, False),
+                                                  (1, 9, 37, 3, 32, True)])
 def test_conv3x3_bwd_direct_vs_torch_autograd(B, H, W, Cin, Cout, nchw):
     """uf_conv3x3_bwd (InputProj form with LeakyReLU' from the stored output, OutputProj form) against torch autograd on the CPU."""
     from uformer_amd import ops

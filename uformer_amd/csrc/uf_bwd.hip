@@ -1758,117 +1758,219 @@ __global__ __launch_bounds__(256) void conv3x3_dx_kernel(const float* __restrict
     }
 }
 
-// Weight gradient, WIDE input side (OutputProj: Cin = 64, Cout = 3).  Block = 3 waves; wave = ky, lane (+64 j) = ci.  A thread walks
-// the columns u of input row y+ky-1 once: x[.][u][ci] is one coalesced load and meets dyeff[y][u+1-kx][co] for kx = 0..2 -- a
-// sliding window of wave-uniform values.  Partial sums of the block's rows go to partial[block][...] in the reference's
-// (Cout,Cin,3,3) order, then db (Cout values, lane 0 of wave 1); column_sum_kernel adds the blocks in order.
+// The same input gradient for the wide-input layer (OutputProj: token rows, Cin % 4 == 0, S = Cout <= 4, no activation mask), WALKING
+// along x: a thread owns 4 input channels of SEG consecutive pixels of one row, holds its 9 x S x 4 weights in registers (they were
+// 108 LDS reads per output pixel) and a 3 x 3 x S window of dy that slides one column per step (3 S loads instead of 9 S).
+template <int S, int SEG>
+__global__ __launch_bounds__(256) void conv3x3_dx_walk_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                              int B, int H, int W, int Cin) {
+    const int groups = Cin / 4, segs = W / SEG;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * H * segs * groups) return;
+    const int c0 = (int)(t % groups) * 4;
+    long long rest = t / groups;
+    const int x0 = (int)(rest % segs) * SEG; rest /= segs;
+    const int y = (int)(rest % H), b = (int)(rest / H);
+    float wr[9][S][4];                                                  // w[co][ci][ky][kx] -> wr[ky*3+kx][co][ci - c0]
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int co = 0; co < S; ++co)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wr[tap][co][e] = w[((size_t)co * Cin + c0 + e) * 9 + tap];
+    // dy rows y + 1, y, y - 1 pair with ky = 0, 1, 2  (dx[q] = sum dy[q - (ky-1, kx-1)] w[ky][kx])
+    const float* rowp[3];
+    float rm[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yp = y - (ky - 1);
+        rm[ky] = (yp >= 0 && yp < H) ? 1.0f : 0.0f;
+        rowp[ky] = dy + ((size_t)b * H + (yp < 0 ? 0 : (yp >= H ? H - 1 : yp))) * W * S;
+    }
+    float win[3][3][S];                                                 // [column slot][ky][co]; slots rotate: columns xx + 1, xx, xx - 1 pair with kx = 0, 1, 2
+    auto load_col = [&](float (&cl)[3][S], int xp) {
+        const float m = (xp >= 0 && xp < W) ? 1.0f : 0.0f;
+        const int xc = xp < 0 ? 0 : (xp >= W ? W - 1 : xp);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int co = 0; co < S; ++co) cl[ky][co] = rowp[ky][(size_t)xc * S + co] * (m * rm[ky]);
+    };
+    auto emit = [&](const float (&cm)[3][S], const float (&cc)[3][S], const float (&cp)[3][S], int xx) {   // columns xx - 1, xx, xx + 1
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float (&cl)[3][S] = kx == 0 ? cp : (kx == 1 ? cc : cm);     // xp = xx - (kx - 1)
+#pragma unroll
+                for (int co = 0; co < S; ++co)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(cl[ky][co], wr[ky * 3 + kx][co][e], acc[e]);
+            }
+        *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + y) * W + xx) * Cin + c0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    };
+    load_col(win[0], x0 - 1);
+    load_col(win[1], x0);
+#pragma unroll 1
+    for (int xs = 0; xs < SEG; xs += 3) {
+        load_col(win[2], x0 + xs + 1);
+        emit(win[0], win[1], win[2], x0 + xs);
+        if (xs + 1 < SEG) { load_col(win[0], x0 + xs + 2); emit(win[1], win[2], win[0], x0 + xs + 1); }
+        if (xs + 2 < SEG) { load_col(win[1], x0 + xs + 3); emit(win[2], win[0], win[1], x0 + xs + 2); }
+    }
+}
+
+// Weight gradient, WIDE input side (OutputProj: Cin = 64, Cout = 3).  Block = one wave, lane (+64 j) = ci.  A thread walks the columns u
+// of an INPUT row once: x[.][u][ci] is one coalesced load and meets dyeff[yi+1-ky][u+1-kx][co] for ky, kx = 0..2 -- sliding windows
+// of wave-uniform values.  Partial sums of the block's rows go to partial[block][...] in the reference's (Cout,Cin,3,3) order, then
+// db (Cout values, lane 0); column_sum_kernel adds the blocks in order.
 template <int S>   // S = Cout <= 4
-__global__ __launch_bounds__(192) void conv3x3_wgrad_wide_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-                                                                    int B, int H, int W, int Cin, int rows_per_block) {
-    const int ky = threadIdx.x >> 6, lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64) void conv3x3_wgrad_wide_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                                   int B, int H, int W, int Cin, int rows_per_block) {
+    const int lane = threadIdx.x;
     const int E = S * Cin * 9 + S;
     float* out = partial + (size_t)blockIdx.x * E;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);    // INPUT rows (b, yi) of this block
     float dbs[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) dbs[s] = 0.f;
     for (int cbase = 0; cbase < Cin; cbase += 64) {
         const int ci = cbase + lane;
         const bool live = ci < Cin;
-        float acc[S][3];
+        float acc[S][3][3];                                                  // [co][ky][kx]
 #pragma unroll
-        for (int s = 0; s < S; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[s][k / 3][k % 3] = 0.f;
         for (int r = r0; r < r1; ++r) {
-            const int b = r / H, y = r - b * H;
-            const int yi = y + ky - 1;
-            if (yi < 0 || yi >= H) continue;                                  // wave-uniform
+            const int b = r / H, yi = r - b * H;
             const float* xr = x + (((size_t)b * H + yi) * W) * Cin + (live ? ci : 0);
-            const float* dr = dy + (((size_t)b * H + y) * W) * S;
-            float d0[S], d1[S], d2[S];                                          // dyeff at columns u-1, u, u+1
+            // input row yi meets the output rows y = yi + 1 - ky: one pass over x for all three (the three waves of the first version each
+            // read the row again)
+            const float* dr[3];
+            float rm[3];
 #pragma unroll
-            for (int s = 0; s < S; ++s) { d0[s] = 0.f; d1[s] = 0.f; d2[s] = dr[s]; }
-            // u = -1 (only kx = 0 would pair x[-1], which is padding): start at u = 0 with the window (dy[-1] = 0, dy[0], dy[1])
+            for (int ky = 0; ky < 3; ++ky) {
+                const int y = yi + 1 - ky;
+                rm[ky] = (y >= 0 && y < H) ? 1.0f : 0.0f;
+                dr[ky] = dy + (((size_t)b * H + (y < 0 ? 0 : (y >= H ? H - 1 : y))) * W) * S;
+            }
+            float d0[3][S], d1[3][S], d2[3][S];                                 // dyeff at columns u-1, u, u+1 (wave-uniform values)
 #pragma unroll
-            for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = W > 1 ? dr[S + s] : 0.f; }
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int s = 0; s < S; ++s) { d0[ky][s] = 0.f; d1[ky][s] = dr[ky][s] * rm[ky]; d2[ky][s] = W > 1 ? dr[ky][S + s] * rm[ky] : 0.f; }
 #pragma unroll 4
             for (int u = 0; u < W; ++u) {
                 const float xv = xr[(size_t)u * Cin];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {                                   // x column u = p.x + kx - 1  ->  p.x = u + 1 - kx
-                    acc[s][0] = fmaf(d2[s], xv, acc[s][0]);
-                    acc[s][1] = fmaf(d1[s], xv, acc[s][1]);
-                    acc[s][2] = fmaf(d0[s], xv, acc[s][2]);
-                }
-                if (cbase == 0 && ky == 1) {
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                    for (int s = 0; s < S; ++s) dbs[s] += d1[s];
+                    for (int s = 0; s < S; ++s) {                               // x column u = p.x + kx - 1  ->  p.x = u + 1 - kx
+                        acc[s][ky][0] = fmaf(d2[ky][s], xv, acc[s][ky][0]);
+                        acc[s][ky][1] = fmaf(d1[ky][s], xv, acc[s][ky][1]);
+                        acc[s][ky][2] = fmaf(d0[ky][s], xv, acc[s][ky][2]);
+                    }
+                if (cbase == 0) {                                               // db: every output pixel once = the ky = 1 pairing (y = yi)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) dbs[s] += d1[1][s];
                 }
 #pragma unroll
-                for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = (u + 2 < W) ? dr[(size_t)(u + 2) * S + s] : 0.f; }
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int s = 0; s < S; ++s) { d0[ky][s] = d1[ky][s]; d1[ky][s] = d2[ky][s]; d2[ky][s] = (u + 2 < W) ? dr[ky][(size_t)(u + 2) * S + s] * rm[ky] : 0.f; }
             }
         }
         if (live) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) out[((s * Cin + ci) * 3 + ky) * 3 + kx] = acc[s][kx];
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) out[((s * Cin + ci) * 3 + ky) * 3 + kx] = acc[s][ky][kx];
         }
     }
-    if (ky == 1 && lane == 0) {
+    if (lane == 0) {
 #pragma unroll
         for (int s = 0; s < S; ++s) out[S * Cin * 9 + s] = dbs[s];
     }
 }
 
-// Weight gradient, WIDE output side (InputProj: Cin = 3 NCHW image, Cout = 32, LeakyReLU' folded in).  Block = 3 waves; wave = ky;
-// lane = (pixel slot, co): a wave covers 64 / Cout pixels per step (Cout 16, 32 or 64).  dyeff[p][co] is the
-// coalesced load; the image values around p are the same address for all lanes of a pixel.  Partials as above.
+// Weight gradient, WIDE output side (InputProj: Cin = 3 NCHW image, Cout = 32, LeakyReLU' folded in).  Block = one wave;
+// lane = (pixel slot, co): the 64 / Cout slots each walk a contiguous run of the row (Cout 16, 32 or 64).  dyeff[p][co] is the
+// coalesced load; the image values around p are the same address for all lanes of a slot.  Partials as above.
 template <int S>   // S = Cin <= 4
-__global__ __launch_bounds__(192) void conv3x3_wgrad_wide_out_kernel(const float* __restrict__ img, const float* __restrict__ dy, const float* __restrict__ act, float slope,
-                                                                     float* __restrict__ partial, int B, int H, int W, int Cout, int rows_per_block) {
-    const int ky = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ppw = 64 / Cout;                                                 // pixels per wave step
+__global__ __launch_bounds__(64) void conv3x3_wgrad_wide_out_kernel(const float* __restrict__ img, const float* __restrict__ dy, const float* __restrict__ act, float slope,
+                                                                    float* __restrict__ partial, int B, int H, int W, int Cout, int rows_per_block) {
+    const int lane = threadIdx.x;
+    const int ppw = 64 / Cout;                                                 // pixel slots per wave
     const int co = lane % Cout, par = lane / Cout;
     const int E = Cout * S * 9 + Cout;
     float* out = partial + ((size_t)blockIdx.x * ppw + par) * E;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);
-    float acc[S][3], dbv = 0.f;
+    const int seg = (W + ppw - 1) / ppw, xa = par * seg, xb = min(W, xa + seg);   // this slot's contiguous run of the row
+    float acc[S][3][3], dbv = 0.f;
 #pragma unroll
-    for (int s = 0; s < S; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[s][k / 3][k % 3] = 0.f;
     for (int r = r0; r < r1; ++r) {
         const int b = r / H, y = r - b * H;
-        const int yi = y + ky - 1;
-        const bool rowok = yi >= 0 && yi < H;                                   // wave-uniform
         const size_t prow = ((size_t)b * H + y) * W;
-        const float* ir = img + ((size_t)b * S * H + (rowok ? yi : 0)) * W;     // plane s at + s*H*W
+        const float* ir[3];
+        float rm[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yi = y + ky - 1;
+            rm[ky] = (yi >= 0 && yi < H) ? 1.0f : 0.0f;
+            ir[ky] = img + ((size_t)b * S * H + (yi < 0 ? 0 : (yi >= H ? H - 1 : yi))) * W;     // plane s at + s*H*W
+        }
+        // the 3 x 3 image window around the pixel slides along the run: S x 3 new values per step (they were 9 S per step, in each of the
+        // three ky waves of the first version, each of which also read dy and the activation again)
+        float win[S][3][3];
+        auto col = [&](int px, int slot) {
+            const float m = (px >= 0 && px < W) ? 1.0f : 0.0f;
+            const int pc = px < 0 ? 0 : (px >= W ? W - 1 : px);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) win[s][ky][slot] = ir[ky][(size_t)s * H * W + pc] * (m * rm[ky]);
+        };
+        col(xa - 1, 1);
+        col(xa, 2);
 #pragma unroll 2
-        for (int px = par; px < W; px += ppw) {
+        for (int px = xa; px < xb; ++px) {
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) { win[s][ky][0] = win[s][ky][1]; win[s][ky][1] = win[s][ky][2]; }
+            col(px + 1, 2);
             const size_t i = (prow + px) * Cout + co;
             const float d = dy[i] * leaky_mask(act, i, slope);
-            if (ky == 1) dbv += d;
-            if (rowok) {
+            dbv += d;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const float* pl = ir + (size_t)s * H * W + px;
-                    const float xl = px > 0 ? pl[-1] : 0.f, xc = pl[0], xr = px + 1 < W ? pl[1] : 0.f;
-                    acc[s][0] = fmaf(d, xl, acc[s][0]);
-                    acc[s][1] = fmaf(d, xc, acc[s][1]);
-                    acc[s][2] = fmaf(d, xr, acc[s][2]);
-                }
-            }
+            for (int s = 0; s < S; ++s)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[s][ky][kx] = fmaf(d, win[s][ky][kx], acc[s][ky][kx]);
         }
     }
 #pragma unroll
     for (int s = 0; s < S; ++s)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) out[((co * S + s) * 3 + ky) * 3 + kx] = acc[s][kx];
-    if (ky == 1) out[Cout * S * 9 + co] = dbv;
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) out[((co * S + s) * 3 + ky) * 3 + kx] = acc[s][ky][kx];
+    out[Cout * S * 9 + co] = dbv;
 }
 
 }  // namespace
 }  // namespace uf
 
-static int conv3x3_bwd_blocks(int B, int H) { const int rows = B * H; return rows < 1024 ? rows : 1024; }
+// one-wave workgroups, each over a few image rows: enough of them to keep ~16 waves per CU streaming (1024 three-wave blocks before)
+static int conv3x3_bwd_blocks(int B, int H) { const int rows = B * H; return rows < 4096 ? rows : 4096; }
 
 extern "C" size_t uf_conv3x3_bwd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
@@ -1887,8 +1989,13 @@ extern "C" int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_conv3x3_bwd: workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     if (dx) {
-        const int grid = grid1d((long long)B * H * W * ((Cin + 3) / 4));
-        hipLaunchKernelGGL(conv3x3_dx_kernel, dim3(grid), dim3(256), 0, st, dy, act_out, slope, w, dx, B, H, W, Cin, Cout, x_nchw);
+        if (wide_in && !act_out && W % 16 == 0 && Cout == 3 && ((uintptr_t)dx % 16) == 0) {    // the OutputProj form: walking kernel
+            const long long n = (long long)B * H * (W / 16) * (Cin / 4);
+            hipLaunchKernelGGL((conv3x3_dx_walk_kernel<3, 16>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dy, w, dx, B, H, W, Cin);
+        } else {
+            const int grid = grid1d((long long)B * H * W * ((Cin + 3) / 4));
+            hipLaunchKernelGGL(conv3x3_dx_kernel, dim3(grid), dim3(256), 0, st, dy, act_out, slope, w, dx, B, H, W, Cin, Cout, x_nchw);
+        }
         if (int rc = check_launch("conv3x3_dx")) return rc;
     }
     const int blocks = conv3x3_bwd_blocks(B, H), rpb = (B * H + blocks - 1) / blocks;
@@ -1897,18 +2004,18 @@ extern "C" int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const
     float* part = (float*)ws;
     if (wide_in) {
         switch (Cout) {
-            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<1>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<2>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<3>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<4>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<1>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<2>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<3>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<4>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
         }
     } else {
         P = blocks * (64 / Cout);
         switch (Cin) {
-            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<1>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
-            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<2>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
-            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<3>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
-            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<4>, dim3(blocks), dim3(192), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<1>, dim3(blocks), dim3(64), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<2>, dim3(blocks), dim3(64), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<3>, dim3(blocks), dim3(64), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
+            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_out_kernel<4>, dim3(blocks), dim3(64), 0, st, x, dy, act_out, slope, part, B, H, W, Cout, rpb); break;
         }
     }
     if (int rc = check_launch("conv3x3_wgrad")) return rc;
