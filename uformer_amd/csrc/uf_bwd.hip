@@ -1821,77 +1821,65 @@ __global__ __launch_bounds__(256) void conv3x3_dx_walk_kernel(const float* __res
     }
 }
 
-// Weight gradient, WIDE input side (OutputProj: Cin = 64, Cout = 3).  Block = one wave, lane (+64 j) = ci.  A thread walks the columns u
-// of an INPUT row once: x[.][u][ci] is one coalesced load and meets dyeff[yi+1-ky][u+1-kx][co] for ky, kx = 0..2 -- sliding windows
-// of wave-uniform values.  Partial sums of the block's rows go to partial[block][...] in the reference's (Cout,Cin,3,3) order, then
-// db (Cout values, lane 0); column_sum_kernel adds the blocks in order.
+// Weight gradient, WIDE input side (OutputProj: Cin = 64, Cout = 3).  Block = 3 waves; wave = ky, lane (+64 j) = ci.  A thread walks
+// the columns u of input row y+ky-1 once: x[.][u][ci] is one coalesced load and meets dyeff[y][u+1-kx][co] for kx = 0..2 -- a
+// sliding window of wave-uniform values.  Partial sums of the block's rows go to partial[block][...] in the reference's
+// (Cout,Cin,3,3) order, then db (Cout values, lane 0 of wave 1); column_sum_kernel adds the blocks in order.
+// (Two rewrites that read the row once for all three ky -- one wave with 27 accumulators per lane, and four waves splitting the columns
+// with an LDS reduction -- measured 649 and 1692 us against 498 us for this form on the 2.1 M x 64 head input: profiles/r03_stemhead.txt.)
 template <int S>   // S = Cout <= 4
-__global__ __launch_bounds__(64) void conv3x3_wgrad_wide_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
-                                                                   int B, int H, int W, int Cin, int rows_per_block) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(192) void conv3x3_wgrad_wide_in_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ partial,
+                                                                    int B, int H, int W, int Cin, int rows_per_block) {
+    const int ky = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int E = S * Cin * 9 + S;
     float* out = partial + (size_t)blockIdx.x * E;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);    // INPUT rows (b, yi) of this block
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(B * H, r0 + rows_per_block);
     float dbs[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) dbs[s] = 0.f;
     for (int cbase = 0; cbase < Cin; cbase += 64) {
         const int ci = cbase + lane;
         const bool live = ci < Cin;
-        float acc[S][3][3];                                                  // [co][ky][kx]
+        float acc[S][3];
 #pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[s][k / 3][k % 3] = 0.f;
+        for (int s = 0; s < S; ++s) acc[s][0] = acc[s][1] = acc[s][2] = 0.f;
         for (int r = r0; r < r1; ++r) {
-            const int b = r / H, yi = r - b * H;
+            const int b = r / H, y = r - b * H;
+            const int yi = y + ky - 1;
+            if (yi < 0 || yi >= H) continue;                                  // wave-uniform
             const float* xr = x + (((size_t)b * H + yi) * W) * Cin + (live ? ci : 0);
-            // input row yi meets the output rows y = yi + 1 - ky: one pass over x for all three (the three waves of the first version each
-            // read the row again)
-            const float* dr[3];
-            float rm[3];
+            const float* dr = dy + (((size_t)b * H + y) * W) * S;
+            float d0[S], d1[S], d2[S];                                          // dyeff at columns u-1, u, u+1
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int y = yi + 1 - ky;
-                rm[ky] = (y >= 0 && y < H) ? 1.0f : 0.0f;
-                dr[ky] = dy + (((size_t)b * H + (y < 0 ? 0 : (y >= H ? H - 1 : y))) * W) * S;
-            }
-            float d0[3][S], d1[3][S], d2[3][S];                                 // dyeff at columns u-1, u, u+1 (wave-uniform values)
+            for (int s = 0; s < S; ++s) { d0[s] = 0.f; d1[s] = 0.f; d2[s] = dr[s]; }
+            // u = -1 (only kx = 0 would pair x[-1], which is padding): start at u = 0 with the window (dy[-1] = 0, dy[0], dy[1])
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int s = 0; s < S; ++s) { d0[ky][s] = 0.f; d1[ky][s] = dr[ky][s] * rm[ky]; d2[ky][s] = W > 1 ? dr[ky][S + s] * rm[ky] : 0.f; }
+            for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = W > 1 ? dr[S + s] : 0.f; }
 #pragma unroll 4
             for (int u = 0; u < W; ++u) {
                 const float xv = xr[(size_t)u * Cin];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int s = 0; s < S; ++s) {                                   // x column u = p.x + kx - 1  ->  p.x = u + 1 - kx
+                    acc[s][0] = fmaf(d2[s], xv, acc[s][0]);
+                    acc[s][1] = fmaf(d1[s], xv, acc[s][1]);
+                    acc[s][2] = fmaf(d0[s], xv, acc[s][2]);
+                }
+                if (cbase == 0 && ky == 1) {
 #pragma unroll
-                    for (int s = 0; s < S; ++s) {                               // x column u = p.x + kx - 1  ->  p.x = u + 1 - kx
-                        acc[s][ky][0] = fmaf(d2[ky][s], xv, acc[s][ky][0]);
-                        acc[s][ky][1] = fmaf(d1[ky][s], xv, acc[s][ky][1]);
-                        acc[s][ky][2] = fmaf(d0[ky][s], xv, acc[s][ky][2]);
-                    }
-                if (cbase == 0) {                                               // db: every output pixel once = the ky = 1 pairing (y = yi)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) dbs[s] += d1[1][s];
+                    for (int s = 0; s < S; ++s) dbs[s] += d1[s];
                 }
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int s = 0; s < S; ++s) { d0[ky][s] = d1[ky][s]; d1[ky][s] = d2[ky][s]; d2[ky][s] = (u + 2 < W) ? dr[ky][(size_t)(u + 2) * S + s] * rm[ky] : 0.f; }
+                for (int s = 0; s < S; ++s) { d0[s] = d1[s]; d1[s] = d2[s]; d2[s] = (u + 2 < W) ? dr[(size_t)(u + 2) * S + s] : 0.f; }
             }
         }
         if (live) {
 #pragma unroll
             for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) out[((s * Cin + ci) * 3 + ky) * 3 + kx] = acc[s][ky][kx];
+                for (int kx = 0; kx < 3; ++kx) out[((s * Cin + ci) * 3 + ky) * 3 + kx] = acc[s][kx];
         }
     }
-    if (lane == 0) {
+    if (ky == 1 && lane == 0) {
 #pragma unroll
         for (int s = 0; s < S; ++s) out[S * Cin * 9 + s] = dbs[s];
     }
@@ -2004,10 +1992,10 @@ extern "C" int uf_conv3x3_bwd(const float* x, int x_nchw, const float* dy, const
     float* part = (float*)ws;
     if (wide_in) {
         switch (Cout) {
-            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<1>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<2>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<3>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
-            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<4>, dim3(blocks), dim3(64), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 1: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<1>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 2: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<2>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            case 3: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<3>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
+            default: hipLaunchKernelGGL(conv3x3_wgrad_wide_in_kernel<4>, dim3(blocks), dim3(192), 0, st, x, dy, part, B, H, W, Cin, rpb); break;
         }
     } else {
         P = blocks * (64 / Cout);
