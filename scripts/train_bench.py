@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--loss-scale", type=float, default=0.0, help="static loss scale (default: 65536 for f16 = GradScaler's initial scale, 1 otherwise)")
     ap.add_argument("--kernels-json", default=None, help="also run ONE instrumented step (HIP events around every library launch) and write the per-(kernel, shape) table here")
+    ap.add_argument("--graph", action="store_true", help="capture forward + backward of one step in a HIP graph (torch.cuda.CUDAGraph) and replay it; AdamW stays outside (its step count is a launch argument)")
     ap.add_argument("--sink", action="store_true", help="use the bucket-view gradient sink on one GPU too (exercises the overlapped path without a collective)")
     a = ap.parse_args()
     rank, local_rank, world = ud.init_process_group("nccl")
@@ -66,6 +67,26 @@ def main():
         return loss
 
     devices = ud.rank_devices("cuda")                                              # all-gathered over RCCL: proof that `world` ranks met
+    if a.graph:
+        # static inputs, a few eager steps on a side stream (allocator and library warm-up, every kernel's one-time attribute calls), then
+        # forward + backward captured once: the gradients live in the graph's private pool and every replay rewrites them in place
+        assert sink is None, "--graph: single-GPU form (the collective of the sink is not captured)"
+        ws = torch.cuda.Stream()
+        ws.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(ws)
+        opt.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = criterion(m(x), target)
+            (static_loss * ls if ls != 1.0 else static_loss).backward()
+
+        def step():                                                                # noqa: F811
+            graph.replay()
+            opt.step(grad_scale=1.0 / ls)
+            return static_loss
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
@@ -81,7 +102,7 @@ def main():
         print(json.dumps({"metric": "training images/sec (fused fwd + recompute bwd + Charbonnier + AdamW kernels)", "value": world * a.batch / dt, "n_gpus": world, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": host_ms,
                           "batch_per_gpu": a.batch, "arch": a.arch, "img": a.img, "dtype": a.dtype, "loss_scale": ls, "loss": float(loss),
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "ranks": world,
-                          "rank_devices": devices,
+                          "rank_devices": devices, "hip_graph": bool(a.graph),
                           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}))
     if a.kernels_json and rank == 0:
         import bench
