@@ -304,6 +304,50 @@ def test_forward_captured_in_a_hip_graph(B):
             assert torch.equal(static_y, want[i]), (B, i, (static_y - want[i]).abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_forward_backward_captured_in_a_hip_graph(dtype):
+    """Forward + backward of a training step inside ONE HIP graph (torch.cuda.CUDAGraph around the module call and loss.backward()): the
+    tape's op kernels, the library's side-stream forks / joins, the torch side stream of the weight-gradient jobs and the caching
+    allocator's private pool all follow the capture.  DropPath off (rate 0) so that eager and replayed steps are comparable: every
+    parameter gradient of a replay must equal the eager gradient bit for bit, also after the static input has been refilled."""
+    import torch.nn.functional as F
+    from uformer_amd import model as um
+    cfg = spec.arch_config("tiny32", img_size=128)
+    m = um.Uformer(img_size=128, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
+                   dd_in=cfg.dd_in, drop_path_rate=0.0, compute_dtype=dtype)
+    m.load_state_dict(spec.synth_state_dict(cfg, 77), strict=True)
+    m = m.cuda().train()
+    xs = [spec.synth_input(2, 128, 128, 50 + i).cuda() for i in range(2)]
+    tg = spec.synth_input(2, 128, 128, 60).cuda()
+
+    def eager(x):
+        m.zero_grad(set_to_none=True)
+        loss = F.l1_loss(m(x), tg)
+        loss.backward()
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    want = [eager(x) for x in xs]
+    static_x = xs[0].clone()
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):                                   # warm-up on the capture stream (workspaces, one-time kernel attributes)
+        eager(static_x)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+    m.zero_grad(set_to_none=True)                                 # the captured backward allocates the gradients in the graph's pool
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        static_loss = F.l1_loss(m(static_x), tg)
+        static_loss.backward()
+    for i in (0, 1, 0):
+        static_x.copy_(xs[i])
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(static_loss.detach(), want[i][0]), (i, static_loss.item(), want[i][0].item())
+        bad = [k for k, p in m.named_parameters() if not torch.equal(p.grad, want[i][1][k])]
+        assert not bad, (i, len(bad), bad[:4])
+
+
 def test_eval_mode_with_mask_and_grad_mode_on_falls_back_with_one_warning():
     """``model.eval(); model(x, mask)`` without torch.no_grad() (grad mode on by default, parameters require grad) used to be
     pushed onto the autograd path, which does not take a mask, and raised.  It now runs the inference kernels (the module-by-module mask
