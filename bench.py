@@ -228,6 +228,18 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
         else:
             ach = dom["flops"] / sec / 1e12
             rf = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS[dtype_name], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS[dtype_name], "traffic": None}
+        # measured HBM bytes per launch of that symbol (scripts/pmc_train.sh: separate FETCH_SIZE / WRITE_SIZE passes of the same step), if
+        # they were taken on exactly these kernel sources
+        for tf in sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic_train.json")), reverse=True):
+            try:
+                tj = json.load(open(tf))
+            except (OSError, ValueError):
+                continue
+            if tj.get("kernel_source_sha") == kernel_source_sha() and name in tj.get("kernels", {}) and dtype_name == "bf16" and B == 32:
+                rf["traffic"] = tj["kernels"][name]["hbm_bytes_per_launch"]
+                rf["traffic_note"] = (f"HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE ({os.path.basename(tf)}); algorithmic bytes per launch "
+                                      f"{dom['bytes'] / max(1, dom['launches']):.3e}; whole step: {tj.get('hbm_bytes_per_step_all_kernels', 0) / 1e9:.1f} GB")
+                break
         rf.update({"kernel": name, "launches_per_step": dom["launches"], "avg_launch_ms": dom["ms"] / max(1, dom["launches"]),
                    "achieved_tflops": dom["flops"] / sec / 1e12, "achieved_gbs": dom["bytes"] / sec / 1e9,
                    "note": "dominant instrumented backward kernel of one training step (HIP events on the launch stream; the step runs single-stream while instrumented)",

@@ -18,6 +18,7 @@ python $R/scripts/rocprof_summary.py /tmp/kt/kt_results.db $O/r03_final | tail -
 rocprofv3 --kernel-trace --stats -d /tmp/kt16 -o kt16 -- python $R/bench.py --dtype f16 --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-train-mode > $O/kt16.log 2>&1
 python $R/scripts/rocprof_summary.py /tmp/kt16/kt16_results.db $O/r03_final_f16 | tail -2
 unset UF_STREAMS
+bash $R/scripts/pmc_train.sh > $O/pmc_train.log 2>&1; grep -E "^pmcT. rc|all kernels" $O/pmc_train.log; cp $O/r03_pmc_traffic_train.json $R/profiles/r03_pmc_traffic_train.json
 rocprofv3 --kernel-trace --stats -d /tmp/ktt -o ktt -- python $R/scripts/train_bench.py --batch 32 --steps 2 --warmup 1 > $O/ktt.log 2>&1
 python $R/scripts/rocprof_summary.py /tmp/ktt/ktt_results.db $O/r03_train_final | tail -2
 (cd $R && python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 --dtype bf16 --kernels-json $O/r03_train_kernels_hip_events.json 2>/dev/null | tail -1;

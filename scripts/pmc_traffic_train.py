@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""HBM traffic of the training step per library timing symbol and in total, from the FETCH_SIZE / WRITE_SIZE passes of
+scripts/pmc_train.sh (<dir>/pmcTC_pmc.csv, <dir>/pmcTD_pmc.csv).  Same corrections as scripts/pmc_traffic.py (KiB -> bytes, FETCH_SIZE x2
+on gfx950).  The passes cover 2 steps (warm-up + 1): bytes are reported per launch of a symbol and per step (= total / 2).
+
+    python scripts/pmc_traffic_train.py gpurun_out profiles/r03_pmc_traffic_train.json"""
+import collections
+import csv
+import json
+import os
+import re
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+STEPS = 2
+
+
+def symbol(kernel):
+    """rocprofv3 kernel name -> (timing symbol of bench.py's train table, counts as a launch of that symbol?)"""
+    k = kernel
+    m = re.search(r"linear_wgrad2?_kernel<uf::(\w+)", k)
+    if m:
+        return f"linear_wgrad_{m.group(1)}", True
+    if "column_sum" in k:
+        return "wgrad_second_stage", True                         # fixed-order sums of the chunk partials (outside the timing scope of linear_wgrad_*)
+    m = re.search(r"gemm_kernel<uf::(\w+), (\d+), \d+, \d+, (\d+), (\d+)>", k)
+    if m:
+        return f"gemm_{m.group(1)}_bn{m.group(2)}_a{m.group(3)}_e{m.group(4)}", True
+    m = re.search(r"window_attn_bwd_kernel<uf::(\w+)", k)
+    if m:
+        return f"window_attn_bwd_{m.group(1)}", True
+    m = re.search(r"window_attn_kernel<uf::(\w+)", k)
+    if m:
+        return f"window_attn_{m.group(1)}", True
+    if "dwconv3x3_bwd" in k:
+        return "dwconv3x3_bwd", "finalize" not in k
+    if "dwconv3x3_walk_kernel" in k or "dwconv3x3_gelu_kernel" in k:
+        return "dwconv3x3_fwd", True
+    if "layernorm_bwd" in k:
+        return "layernorm_bwd", True
+    if "layernorm_kernel" in k:
+        return "layernorm", True
+    if "grad_fork" in k or "residual_combine" in k:
+        return "streaming_helpers", True
+    return "other", True
+
+
+def load(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        s, counts = symbol(r["kernel"])
+        n = int(r["dispatches"])
+        acc[s][0] += float(r[counter]) * 1024.0 * n
+        acc[s][1] += n if counts else 0
+    return acc
+
+
+fetch, write = load(f"{src}/pmcTC_pmc.csv", "FETCH_SIZE"), load(f"{src}/pmcTD_pmc.csv", "WRITE_SIZE")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+out, tot = {}, 0.0
+for s in sorted(fetch):
+    f, n = fetch[s]
+    w = write.get(s, [0.0, 0])[0]
+    hbm = 2.0 * f + w
+    tot += hbm
+    out[s] = {"hbm_bytes_per_step": hbm / STEPS, "fetch_bytes_per_step": 2.0 * f / STEPS, "write_bytes_per_step": w / STEPS, "launches_per_step": n / STEPS,
+              "hbm_bytes_per_launch": hbm / max(1, n)}
+json.dump({"kernel_source_sha": bench.kernel_source_sha(),
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python scripts/train_bench.py --batch 32 --steps 1 --warmup 1 (Uformer-B 256^2, bf16); "
+                     "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; per symbol: all launches of 2 steps / 2",
+           "hbm_bytes_per_step_all_kernels": tot / STEPS, "kernels": out}, open(dst, "w"), indent=1)
+print(f"all kernels: {tot / STEPS / 1e9:.1f} GB of HBM traffic per training step")
+for s, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_step"]):
+    print(f"{s:34s} {v['hbm_bytes_per_step'] / 1e9:7.2f} GB/step  {v['launches_per_step']:6.0f} launches  {v['hbm_bytes_per_launch'] / 1e6:8.1f} MB/launch")

@@ -739,21 +739,36 @@ __device__ __forceinline__ unsigned wg2_off(int row, int chunk) {     // byte of
     return (unsigned)(row * 256 + ((chunk ^ (rho << 2)) << 3));
 }
 
+// Workgroup -> (tile, token chunk): the tiles of ONE chunk read the same dY / X rows (dY once per K tile column, X once per N tile
+// row), and workgroup L runs on XCD L % 8 with its own L2.  As a (tiles, chunks) grid the tiles of a chunk landed on eight different
+// XCDs and every one of them fetched the rows for itself: 460 MB of HBM traffic per launch against 129 MB algorithmic, 77 GB of the
+// 337 GB a training step moved (profiles/r03_pmc_traffic_train.json, first version).  Now the grid is linear and XCD x walks
+// chunks x, x + 8, ... with the tiles of a chunk on consecutive workgroups of that XCD.  Placement only: same partials, same sums.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ X, int ldx,
-                                                               float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K) {
+                                                               float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K, int S, int xcd_map) {
     __shared__ __attribute__((aligned(16))) char Ys[2][32 * 256];
     __shared__ __attribute__((aligned(16))) char Xs[2][32 * 256];
     __shared__ float Bs[16][128 + 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int k_tiles = (K + 127) / 128;
-    const int n0 = (blockIdx.x / k_tiles) * 128, k0 = (blockIdx.x % k_tiles) * 128;
+    const int k_tiles = (K + 127) / 128, tiles = ((N + 127) / 128) * k_tiles;
+    int tile, chunk;
+    if (xcd_map) {
+        const int xcd = (int)blockIdx.x & 7, seq = (int)blockIdx.x >> 3;
+        tile = seq % tiles;
+        chunk = (seq / tiles) * 8 + xcd;
+        if (chunk >= S) return;                              // whole workgroup (the grid is padded to 8 chunk lanes)
+    } else {
+        tile = (int)blockIdx.x % tiles;
+        chunk = (int)blockIdx.x / tiles;
+    }
+    const int n0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
     const int wn = wave >> 1, wk = wave & 1;                 // 64 x 64 quadrant of this wave
-    const bool do_bias = (blockIdx.x % k_tiles) == 0;
+    const bool do_bias = (tile % k_tiles) == 0;
     const int steps_all = (M + 31) / 32;
-    const int s0 = (int)((long long)steps_all * blockIdx.y / gridDim.y), s1 = (int)((long long)steps_all * (blockIdx.y + 1) / gridDim.y);
+    const int s0 = (int)((long long)steps_all * chunk / S), s1 = (int)((long long)steps_all * (chunk + 1) / S);
 
     // loader role: pieces pc = tid and tid + 256 of each [32][128] tile: row pc >> 4, 16-byte piece pc & 15 (same piece for both)
     const int prow = tid >> 4, pseg = tid & 15;
@@ -845,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restri
         __syncthreads();
     }
     // ---- partial tile: D row = 4*fg + reg -> n, col = fr -> k
-    float* wp = ws_w + (size_t)blockIdx.y * N * K;
+    float* wp = ws_w + (size_t)chunk * N * K;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -863,7 +878,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restri
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += Bs[r][tid];
-            ws_b[(size_t)blockIdx.y * N + n0 + tid] = t;
+            ws_b[(size_t)chunk * N + n0 + tid] = t;
         }
     }
 }
@@ -1287,8 +1302,10 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype_name(dtype), M, N, K);
     {
         ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
-        if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K);
-        else if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel<f16>, grid, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K);
+        static const int xcd_map = !(getenv("UF_WGRAD_XCD") && atoi(getenv("UF_WGRAD_XCD")) == 0);          // 0: chunk-major order (A/B)
+        const dim3 grid2((unsigned)(grid.x * (xcd_map ? (S + 7) / 8 * 8 : S)));
+        if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid2, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
+        else if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel<f16>, grid2, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
         else UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(linear_wgrad_kernel<TT>, grid, dim3(256), 0, st, (const TT*)dY, ldy, (const TT*)X, ldx, ws_w, ws_b, M, N, K));
     }
     int rc = check_launch("linear_wgrad");
