@@ -1,0 +1,357 @@
+// Microbenchmark / prototype for DESIGN.md section 7.1: how should the K tiles of the bf16 GEMM reach LDS?
+//   MODE 0  register-staged: global_load_dwordx4 -> VGPRs -> ds_write_b128 into rows padded to 144 bytes (what uf_gemm.hip does)
+//   MODE 1  LDS-DMA: global_load_lds_dwordx4 straight into unpadded 128-byte rows; the bank-conflict-free placement (16-byte chunk c of row
+//           r at position c ^ (r & 7)) is obtained by permuting WHICH global chunk a lane fetches, not where it lands
+// Both: D[m][n] = sum_k A[m][k] W[n][k], bf16 in, f32 accumulate, bf16 out; 128 x 128 tiles, K tiles of 64, two LDS buffers, 4 waves of
+// 64 x 64, two workgroups per CU, XCD-aware tile order, the same (simple, unstaged) epilogue -- so the difference is the staging path.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 gemm_dma.hip -o gemm_dma && ./gemm_dma
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    const bf2 r = __builtin_convertvector(f2{lo, hi}, bf2);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+__device__ __forceinline__ void dma_global_to_lds(const void* src, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(src) : "memory");
+}
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_proto(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wt, uint16_t* __restrict__ D, int M, int N, int K) {
+    constexpr int ROWB = MODE == 0 ? 144 : 128;
+    constexpr int BUF = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_tiles = N / BN;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int mt = (seq / n_tiles) * 8 + xcd;
+    if (mt * BM >= M) return;
+    const int m0 = mt * BM, n0 = (seq % n_tiles) * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = K / BK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- staging
+    const int ccol = tid & 7, crow = tid >> 3;            // MODE 0: chunk column, first row
+    u32x4 ra[4], rw[4];
+    auto g_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const u32x4*>(A + (size_t)(m0 + crow + 32 * i) * K + t * BK + ccol * 8);
+            rw[i] = *reinterpret_cast<const u32x4*>(Wt + (size_t)(n0 + crow + 32 * i) * K + t * BK + ccol * 8);
+        }
+    };
+    auto s_store = [&](int buf) {
+        char* As = smem + buf * BUF;
+        char* Ws = As + BM * ROWB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(As + (crow + 32 * i) * ROWB + ccol * 16) = ra[i];
+            *reinterpret_cast<u32x4*>(Ws + (crow + 32 * i) * ROWB + ccol * 16) = rw[i];
+        }
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma_tile = [&](int t, int buf) {                  // wave w moves rows [32 w, 32 w + 32) of both operands: 4 + 4 instructions of 8 rows
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 32 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            dma_global_to_lds(A + (size_t)(m0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + (wave * 32 + q * 8) * 128);
+            dma_global_to_lds(Wt + (size_t)(n0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + BM * 128 + (wave * 32 + q * 8) * 128);
+        }
+    };
+
+    if (MODE == 0) { g_load(0); s_store(0); }
+    else { dma_tile(0, 0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) { if (MODE == 0) g_load(t + 1); else dma_tile(t + 1, buf ^ 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = smem + buf * BUF;
+        const char* Ws = As + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[4], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int R = wm * 64 + j * 16 + fr, cw = ks * 4 + fg;
+                af[j] = *reinterpret_cast<const u32x4*>(As + R * ROWB + (MODE == 0 ? cw : (cw ^ (R & 7))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int R = wn * 64 + i * 16 + fr, cw = ks * 4 + fg;
+                wf[i] = *reinterpret_cast<const u32x4*>(Ws + R * ROWB + (MODE == 0 ? cw : (cw ^ (R & 7))) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, af[j]), acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) { if (MODE == 0) s_store(buf ^ 1); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __syncthreads();
+    }
+    // epilogue: lane holds n = .. + fg*4 + {0..3} of token m = .. + fr
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4, m = m0 + wm * 64 + j * 16 + fr;
+            *reinterpret_cast<u32x2*>(D + (size_t)m * N + n) = u32x2{pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3])};
+        }
+}
+
+// MODE 2: 256 x 128 tiles, 8 waves (4 x 2 of 64 x 64), THREE LDS stages of 48 KiB filled by DMA two K tiles ahead, one workgroup per CU.
+// No staging registers, so the deeper ring costs only LDS; the W tile is shared by twice the rows.
+template <int NS>
+__global__ __launch_bounds__(512, 1) void gemm_proto_big(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wt, uint16_t* __restrict__ D, int M, int N, int K) {
+    constexpr int BMB = 256, STAGE = (BMB + BN) * 128;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_tiles = N / BN;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int mt = (seq / n_tiles) * 8 + xcd;
+    if (mt * BMB >= M) return;
+    const int m0 = mt * BMB, n0 = (seq % n_tiles) * BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = K / BK;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma_tile = [&](int t, int stage) {                // wave w: rows [32 w, 32 w + 32) of A (4 instructions), rows [16 w, 16 w + 16) of W (2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 32 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            dma_global_to_lds(A + (size_t)(m0 + r) * K + t * BK + c * 8, lds0 + stage * STAGE + (wave * 32 + q * 8) * 128);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = wave * 16 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            dma_global_to_lds(Wt + (size_t)(n0 + r) * K + t * BK + c * 8, lds0 + stage * STAGE + BMB * 128 + (wave * 16 + q * 8) * 128);
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < NS - 1; ++d)
+        if (d < nt) dma_tile(d, d);
+    if (nt > NS - 2) { if (NS == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + NS - 1 < nt) { int st2 = stage + NS - 1; if (st2 >= NS) st2 -= NS; dma_tile(t + NS - 1, st2); }
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = smem + stage * STAGE;
+        const char* Ws = As + BMB * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[4], wf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int R = wm * 64 + j * 16 + fr, cw = ks * 4 + fg;
+                af[j] = *reinterpret_cast<const u32x4*>(As + R * 128 + (cw ^ (R & 7)) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int R = wn * 64 + i * 16 + fr, cw = ks * 4 + fg;
+                wf[i] = *reinterpret_cast<const u32x4*>(Ws + R * 128 + (cw ^ (R & 7)) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, af[j]), acc[i][j], 0, 0, 0);
+        }
+        // tile t + 1 must have landed; the tile issued in this step (6 instructions per wave) may still fly
+        if (NS == 3 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (++stage == NS) stage = 0;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + i * 16 + fg * 4, m = m0 + wm * 64 + j * 16 + fr;
+            *reinterpret_cast<u32x2*>(D + (size_t)m * N + n) = u32x2{pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3])};
+        }
+}
+
+// MODE 4: MODE 1 made persistent: 512 workgroups (two per CU) walk the tiles; the K-tile stream continues across tile boundaries, so
+// the first K tile of the NEXT output tile is already flying (DMA) while the finished tile is packed and stored, and the stores
+// themselves drain under the next tile's MFMAs (vector memory returns in order: the DMA is older than the stores, so the wait in
+// front of the barrier leaves the 16 stores outstanding).
+__global__ __launch_bounds__(256, 2) void gemm_proto_persist(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wt, uint16_t* __restrict__ D, int M, int N, int K) {
+    constexpr int BUF = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_tiles = N / BN, m_tiles = M / BM;
+    const int VB = ((m_tiles + 7) / 8) * 8 * n_tiles;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nt = K / BK;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto coords = [&](int v, int& m0, int& n0) {             // virtual block -> tile origin (XCD-aware order of gemm_proto); false if padding
+        const int seq = v >> 3, xcd = v & 7;
+        const int mt = (seq / n_tiles) * 8 + xcd;
+        m0 = mt * BM; n0 = (seq % n_tiles) * BN;
+        return mt < m_tiles;
+    };
+    auto next_valid = [&](int v) { int a, b; while (v < VB && !coords(v, a, b)) v += gridDim.x; return v; };
+    auto dma_tile = [&](int m0, int n0, int t, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = wave * 32 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            dma_global_to_lds(A + (size_t)(m0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + (wave * 32 + q * 8) * 128);
+            dma_global_to_lds(Wt + (size_t)(n0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + BM * 128 + (wave * 32 + q * 8) * 128);
+        }
+    };
+    int v = next_valid((int)blockIdx.x);
+    if (v >= VB) return;
+    int m0, n0;
+    coords(v, m0, n0);
+    dma_tile(m0, n0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int buf = 0;
+    while (v < VB) {
+        const int vn = next_valid(v + (int)gridDim.x);
+        int m1 = 0, n1 = 0;
+        const bool more = vn < VB;
+        if (more) coords(vn, m1, n1);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nt; ++t) {
+            const bool last = t + 1 == nt;
+            if (!last) dma_tile(m0, n0, t + 1, buf ^ 1);
+            else if (more) dma_tile(m1, n1, 0, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const char* As = smem + buf * BUF;
+            const char* Ws = As + BM * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                u32x4 af[4], wf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int R = wm * 64 + j * 16 + fr, cw = ks * 4 + fg;
+                    af[j] = *reinterpret_cast<const u32x4*>(As + R * 128 + (cw ^ (R & 7)) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int R = wn * 64 + i * 16 + fr, cw = ks * 4 + fg;
+                    wf[i] = *reinterpret_cast<const u32x4*>(Ws + R * 128 + (cw ^ (R & 7)) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, af[j]), acc[i][j], 0, 0, 0);
+            }
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = n0 + wn * 64 + i * 16 + fg * 4, m = m0 + wm * 64 + j * 16 + fr;
+                        *reinterpret_cast<u32x2*>(D + (size_t)m * N + n) = u32x2{pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3])};
+                    }
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // the DMA above is older than the 16 stores: they may stay in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        v = vn; m0 = m1; n0 = n1;
+    }
+}
+
+static float bf2f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+
+int main() {
+    struct Shape { int M, N, K; const char* what; };
+    const Shape shapes[] = {{131072, 256, 1024, "dz dec1 (N=C, K=4C)"}, {131072, 1024, 256, "fc1 dec1"}, {32768, 512, 2048, "dz dec0"}, {32768, 2048, 512, "fc1 dec0"},
+                            {524288, 128, 512, "dz dec2"}, {131072, 256, 768, "dxn dec1"}};
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (const Shape& s : shapes) {
+        const size_t na = (size_t)s.M * s.K, nw = (size_t)s.N * s.K, nd = (size_t)s.M * s.N;
+        std::vector<uint16_t> ha(na), hw(nw);
+        uint32_t seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto& v : ha) v = f2bf(rnd());
+        for (auto& v : hw) v = f2bf(rnd() * 0.1f);
+        uint16_t *dA, *dW, *dD;
+        hipMalloc(&dA, na * 2); hipMalloc(&dW, nw * 2); hipMalloc(&dD, nd * 2);
+        hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice); hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
+        const int m_tiles = s.M / BM, n_tiles = s.N / BN;
+        const dim3 grid128((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
+        auto run = [&](int mode, const char* name) {
+            const int smem = (mode <= 1 || mode == 4) ? 2 * (BM + BN) * (mode == 0 ? 144 : 128) : (mode == 2 ? 3 : 2) * (256 + BN) * 128;
+            void (*kern)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int) =
+                mode == 0 ? gemm_proto<0> : (mode == 1 ? gemm_proto<1> : (mode == 2 ? gemm_proto_big<3> : (mode == 3 ? gemm_proto_big<2> : gemm_proto_persist)));
+            const dim3 grid = mode <= 1 ? grid128 : (mode == 4 ? dim3(grid128.x < 512u ? grid128.x : 512u) : dim3((unsigned)(((s.M / 256 + 7) / 8) * 8 * n_tiles)));
+            const int threads = (mode <= 1 || mode == 4) ? 256 : 512;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipMemset(dD, 0, nd * 2);
+            float best = 1e30f;
+            for (int r = 0; r < 5; ++r) {
+                hipEventRecord(e0);
+                hipLaunchKernelGGL(kern, grid, dim3(threads), smem, 0, dA, dW, dD, s.M, s.N, s.K);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (r > 0 && ms < best) best = ms;
+            }
+            // spot check 64 outputs against the host
+            std::vector<uint16_t> hd(nd);
+            hipMemcpy(hd.data(), dD, nd * 2, hipMemcpyDeviceToHost);
+            double worst = 0;
+            for (int q = 0; q < 64; ++q) {
+                const size_t m = ((size_t)q * 2654435761u) % s.M, n = ((size_t)q * 40503u + 17) % s.N;
+                double ref = 0;
+                for (int k = 0; k < s.K; ++k) ref += (double)bf2f(ha[m * s.K + k]) * bf2f(hw[n * s.K + k]);
+                const double err = fabs(ref - bf2f(hd[m * s.N + n])) / (fabs(ref) + 1e-2);
+                if (err > worst) worst = err;
+            }
+            printf("%-22s %7dx%5dx%5d  %-34s %8.1f us  %7.1f TFLOP/s  rel err %.1e%s\n", s.what, s.M, s.N, s.K, name, best * 1e3, 2.0 * s.M * s.N * s.K / best / 1e9, worst,
+                   worst < 2e-2 ? "" : "  <-- WRONG");
+        };
+        run(0, "registers -> ds_write_b128");
+        run(1, "LDS-DMA, XOR-placed chunks");
+        run(2, "DMA, 256x128, 8 waves, 3 stages");
+        run(4, "DMA, persistent, stores under MFMA");
+        hipFree(dA); hipFree(dW); hipFree(dD);
+    }
+    return 0;
+}
