@@ -297,6 +297,74 @@ __global__ __launch_bounds__(256, 2) void gemm_proto_persist(const uint16_t* __r
     }
 }
 
+// MODE 6: MODE 1 with EIGHT waves per 128 x 128 tile (2 x 4 of 64 x 32): four waves per SIMD instead of two to hide the fragment reads.
+__global__ __launch_bounds__(512, 2) void gemm_proto_w8(const uint16_t* __restrict__ A, const uint16_t* __restrict__ Wt, uint16_t* __restrict__ D, int M, int N, int K) {
+    constexpr int BUF = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_tiles = N / BN;
+    const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int mt = (seq / n_tiles) * 8 + xcd;
+    if (mt * BM >= M) return;
+    const int m0 = mt * BM, n0 = (seq % n_tiles) * BN;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nt = K / BK;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto dma_tile = [&](int t, int buf) {                  // wave w: rows [16 w, 16 w + 16) of both operands
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = wave * 16 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            dma_global_to_lds(A + (size_t)(m0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + (wave * 16 + q * 8) * 128);
+            dma_global_to_lds(Wt + (size_t)(n0 + r) * K + t * BK + c * 8, lds0 + buf * BUF + BM * 128 + (wave * 16 + q * 8) * 128);
+        }
+    };
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) dma_tile(t + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = smem + buf * BUF;
+        const char* Ws = As + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 af[4], wf[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int R = wm * 64 + j * 16 + fr, cw = ks * 4 + fg;
+                af[j] = *reinterpret_cast<const u32x4*>(As + R * 128 + (cw ^ (R & 7)) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int R = wn * 32 + i * 16 + fr, cw = ks * 4 + fg;
+                wf[i] = *reinterpret_cast<const u32x4*>(Ws + R * 128 + (cw ^ (R & 7)) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, af[j]), acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 32 + i * 16 + fg * 4, m = m0 + wm * 64 + j * 16 + fr;
+            *reinterpret_cast<u32x2*>(D + (size_t)m * N + n) = u32x2{pack2(acc[i][j][0], acc[i][j][1]), pack2(acc[i][j][2], acc[i][j][3])};
+        }
+}
+
 // MODE 5: 256 x 256 tiles, 4 waves of 128 x 128 (64 accumulator tiles = 256 registers, the AGPR half of the file), two 64 KiB DMA stages,
 // one workgroup per CU: 128 MFMAs per 32 fragment reads per wave and K tile (the register-staged form of this tiling measured no better than
 // 128 x 128 in the library; here the staging stores are gone).
@@ -388,12 +456,12 @@ int main() {
         const int m_tiles = s.M / BM, n_tiles = s.N / BN;
         const dim3 grid128((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
         auto run = [&](int mode, const char* name) {
-            const int smem = mode == 5 ? 2 * 512 * 128 : (mode <= 1 || mode == 4) ? 2 * (BM + BN) * (mode == 0 ? 144 : 128) : (mode == 2 ? 3 : 2) * (256 + BN) * 128;
+            const int smem = mode == 5 ? 2 * 512 * 128 : (mode <= 1 || mode == 4 || mode == 6) ? 2 * (BM + BN) * (mode == 0 ? 144 : 128) : (mode == 2 ? 3 : 2) * (256 + BN) * 128;
             void (*kern)(const uint16_t*, const uint16_t*, uint16_t*, int, int, int) =
-                mode == 0 ? gemm_proto<0> : (mode == 1 ? gemm_proto<1> : (mode == 2 ? gemm_proto_big<3> : (mode == 3 ? gemm_proto_big<2> : (mode == 4 ? gemm_proto_persist : gemm_proto_huge))));
+                mode == 0 ? gemm_proto<0> : (mode == 1 ? gemm_proto<1> : (mode == 2 ? gemm_proto_big<3> : (mode == 3 ? gemm_proto_big<2> : (mode == 4 ? gemm_proto_persist : (mode == 5 ? gemm_proto_huge : gemm_proto_w8)))));
             if (mode == 5 && (s.N % 256 || s.M % 256)) return;
-            const dim3 grid = mode == 5 ? dim3((unsigned)(((s.M / 256 + 7) / 8) * 8 * (s.N / 256))) : mode <= 1 ? grid128 : (mode == 4 ? dim3(grid128.x < 512u ? grid128.x : 512u) : dim3((unsigned)(((s.M / 256 + 7) / 8) * 8 * n_tiles)));
-            const int threads = (mode <= 1 || mode >= 4) ? 256 : 512;
+            const dim3 grid = mode == 6 ? grid128 : mode == 5 ? dim3((unsigned)(((s.M / 256 + 7) / 8) * 8 * (s.N / 256))) : mode <= 1 ? grid128 : (mode == 4 ? dim3(grid128.x < 512u ? grid128.x : 512u) : dim3((unsigned)(((s.M / 256 + 7) / 8) * 8 * n_tiles)));
+            const int threads = (mode <= 1 || mode == 4 || mode == 5) ? 256 : 512;
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             hipMemset(dD, 0, nd * 2);
             float best = 1e30f;
@@ -423,6 +491,7 @@ int main() {
         run(2, "DMA, 256x128, 8 waves, 3 stages");
         run(4, "DMA, persistent, stores under MFMA");
         run(5, "DMA, 256x256, 4 waves of 128x128");
+        run(6, "DMA, 128x128, 8 waves of 64x32");
         hipFree(dA); hipFree(dW); hipFree(dD);
     }
     return 0;
