@@ -30,6 +30,31 @@ struct Leff2Params {
 
 constexpr int KCW = 64;  // hidden channels one producer group (4 waves) convolves per interval
 
+// UF_MCONV: how the producers of the 2-byte operand types evaluate the depthwise 3x3 (round 4).
+//   0  VALU stencil (rounds 1-3): 9 FMAs per output + one bf16->f32 unpack per (output, column tap) -- 298 VALU instructions per producer
+//      wave and interval; the PMC passes of round 3 show the VALU pipe of a SIMD (one wave-instruction per 4 cycles) as the busiest
+//      resource of this kernel (47-55 % at every width), the MFMA pipe at 5-19 %.
+//   1  MFMA stencil, taps rounded to the operand type: a 16-channel group of a 16-pixel tile is D[c][p] = sum_k A[c][k] B[k][p] with
+//      k = (tap, c'), A[c][(tap, c')] = w[tap][c] delta(c, c') (a block-diagonal weight operand built in registers: one non-zero 16-bit
+//      slot per lane) and B[(tap, c')][p] = halo[p + tap][c'] = a 16-byte ds_read_b128 of the DMA-staged halo tile AS IT LIES in LDS --
+//      no unpack, no FMA on the VALU; 15/16 of the MFMA's multiplies are zeros, on a pipe that is idle.  K = 9 taps x 16 = 5 k-steps
+//      of 32 (two taps per step).  The accumulator starts at the conv bias, GELU runs on the accumulator registers, and the result is
+//      written to the operand tile of linear2 exactly as before.
+//   2  the same with every tap split into hi + lo parts of the operand type (9 k-steps: slots = {hi, lo} x 16 channels): products of
+//      2-byte operands are exact in the f32 accumulator, so the taps count with 16 (bf16) / 22 (f16) mantissa bits -- the f32 taps of
+//      the VALU form to 2^-17; only the summation order differs.  Default: the result stays inside the f32-tap error budget.
+#ifndef UF_MCONV
+#define UF_MCONV 2
+#endif
+template <typename T> __device__ __forceinline__ unsigned cvt16(float f);
+template <> __device__ __forceinline__ unsigned cvt16<bf16>(float f) { return f2bf(f); }
+template <> __device__ __forceinline__ unsigned cvt16<f16>(float f) { return f2h(f); }
+template <> __device__ __forceinline__ unsigned cvt16<float>(float) { return 0; }
+template <typename T> __device__ __forceinline__ float back16(unsigned h);
+template <> __device__ __forceinline__ float back16<bf16>(unsigned h) { return bf2f((uint16_t)h); }
+template <> __device__ __forceinline__ float back16<f16>(unsigned h) { return h2f((uint16_t)h); }
+template <> __device__ __forceinline__ float back16<float>(unsigned) { return 0.f; }
+
 template <typename T> __device__ __forceinline__ void cvt8(const char* p, float* f);
 template <> __device__ __forceinline__ void cvt8<bf16>(const char* p, float* f) { unpack8<bf16>(*reinterpret_cast<const u32x4*>(p), f); }
 template <> __device__ __forceinline__ void cvt8<f16>(const char* p, float* f) { unpack8<f16>(*reinterpret_cast<const u32x4*>(p), f); }
@@ -83,6 +108,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int n) {
 template <typename T, int C, int NPG, int NC, int NBUF, int WPS>
 __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const Leff2Params p) {
     constexpr int NP = 4 * NPG;                   // producer waves
+    constexpr int MC = sizeof(T) == 2 ? UF_MCONV : 0;   // depthwise 3x3 on the MFMA (2-byte operand types), see UF_MCONV
     constexpr int SR = 2;                         // rows of the column strip one producer thread convolves
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
@@ -143,7 +169,10 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                 const int hp = q / CPP, part = q - hp * CPP;
                 const int hy = hp / HW_, hx = hp - hy * HW_;
                 const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-                if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) voff[s] = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + part * 16);
+                // MFMA stencil: slot `part` of a halo pixel holds its 16-byte piece part ^ (hx & 6) -- the placement that makes the B-fragment
+                // reads (16 lanes = 16 pixels at a 128-byte stride) conflict-free; a lane fetches the piece that belongs where it lands
+                const int piece = MC ? (part ^ (hx & 6)) : part;
+                if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) voff[s] = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + piece * 16);
             }
         }
         auto issue = [&](int it) {                              // all DMA of interval `it` into ring slot it % NBUF
@@ -168,6 +197,21 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
         const int grp = wave >> 2;                              // producer group
         const int gt = tid & 255;                               // thread index within the group
         const int cvec = gt & 7, sx = (gt >> 3) & 7, sy0 = (gt >> 6) * SR;
+        // MFMA stencil: the wave's 16-channel group, the lane's non-zero slot of the block-diagonal weight fragments, and the byte offsets
+        // of its B fragments (pixel tile 0; tile pt adds two halo rows) per k-step
+        const int gq = wave & 3;
+        const unsigned hshift = (fr & 1) * 16;
+        unsigned msk[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) msk[d] = ((fg & 1) == (fr >> 3) && d == ((fr & 7) >> 1)) ? 0xffffffffu : 0u;
+        int boff[MC == 2 ? 9 : 5];
+#pragma unroll
+        for (int ks = 0; ks < (MC == 2 ? 9 : 5); ++ks) {
+            int tap = MC == 2 ? ks : 2 * ks + (fg >> 1);
+            tap = tap < 9 ? tap : 8;
+            const int hy = (fr >> 3) + tap / 3, hx = (fr & 7) + tap % 3;
+            boff[ks] = ((hy * HW_ + hx) * 8 + ((gq * 2 + (fg & 1)) ^ (hx & 6))) * 16;
+        }
 #pragma unroll
         for (int it = 0; it < NBUF - 1; ++it)
             if (it < NIT) issue(it);
@@ -181,6 +225,45 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                 const char* Hs = Ring + (i % NBUF) * BUFB + grp * HGB;
                 const float* Wl = reinterpret_cast<const float*>(Ring + (i % NBUF) * BUFB + NPG * HGB) + grp * KCW;
                 char* At = At0 + (i & 1) * AT_BYTES + grp * KCW * SZ;
+                if constexpr (MC != 0) {
+                    // ---- depthwise 3x3 on the MFMA: this wave = the 16-channel group gq of its 64-channel halo tile, all 4 pixel tiles ----
+                    constexpr int NKS = MC == 2 ? 9 : 5;
+                    const float* wc = Wl + gq * 16 + fr;                  // this lane's channel in the tap table [10][KC]
+                    Frag<T> af[NKS];
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+                        unsigned v16;
+                        if constexpr (MC == 2) {                          // k-step = tap ks; lane groups 0,1: hi part, 2,3: lo part
+                            const float w = wc[ks * KC];
+                            const unsigned hi = cvt16<T>(w);
+                            v16 = (fg >> 1) ? cvt16<T>(w - back16<T>(hi)) : hi;
+                        } else {                                          // k-step = taps 2ks (lane groups 0,1) and 2ks+1 (2,3); tap 9 = padding
+                            const int tap = 2 * ks + (fg >> 1);
+                            const float w = wc[(tap < 9 ? tap : 8) * KC];
+                            v16 = tap < 9 ? cvt16<T>(w) : 0u;
+                        }
+                        const unsigned sh = v16 << hshift;
+                        af[ks].v = u32x4{sh & msk[0], sh & msk[1], sh & msk[2], sh & msk[3]};
+                    }
+                    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(Wl + 9 * KC + gq * 16 + fg * 4);
+                    f32x4 cacc[4];
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) cacc[pt] = bias4;
+#pragma unroll
+                    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                        for (int pt = 0; pt < 4; ++pt) {
+                            Frag<T> bf;
+                            bf.v = *reinterpret_cast<const u32x4*>(Hs + boff[ks] + pt * (2 * HW_ * PS));
+                            mma16(cacc[pt], af[ks], bf);                  // weights as A: lane = pixel fr, channels 4 fg .. 4 fg + 3
+                        }
+                    }
+#pragma unroll
+                    for (int pt = 0; pt < 4; ++pt) {
+                        gelu4<T>(cacc[pt]);
+                        store4(reinterpret_cast<T*>(At + (pt * 16 + fr) * SAT) + gq * 16 + fg * 4, cacc[pt]);
+                    }
+                } else {
                 float o[SR][8];
 #pragma unroll
                 for (int r = 0; r < SR; ++r)
@@ -210,6 +293,7 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                 for (int r = 0; r < SR; ++r) {
                     gelu_n<T, 8>(o[r]);
                     put8(reinterpret_cast<T*>(At + ((sy0 + r) * TW + sx) * SAT) + cvec * 8, o[r]);
+                }
                 }
             }
             t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
