@@ -176,6 +176,39 @@ def test_gemm_training_shapes(ops, dtype, M, N, K):
     assert ((outw - refw).abs().max() / refw.abs().max()).item() < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (16384, 256, 1024), (1000, 192, 512), (2048, 1024, 256), (4096, 64, 128), (320, 1536, 512), (130, 96, 128), (4096, 768, 256), (8192, 1536, 512)])
+def test_gemm_dma_bit_identical(ops, dtype, M, N, K, monkeypatch):
+    """The LDS-DMA staging path of the GEMM (uf_gemm.hip; K-heavy products of the plain loader) against the register-staged path it replaced,
+    through every epilogue: the same MFMAs on the same operands in the same order, so the results must agree bit for bit -- including row / column
+    tails (M, N not multiples of the tile) that the DMA path fills through the buffer descriptor's bounds check."""
+    gen = torch.Generator().manual_seed(7 * M + N + K)
+    a = (torch.randn(M, K, generator=gen) + torch.arange(M)[:, None] * 1e-4).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+    prev = torch.randn(M, N, generator=gen).to(dtype).cuda()
+    x = torch.randn(M, N, generator=gen).cuda()
+
+    def run_all():
+        outs = [ops.linear(a, w, b), ops.linear(a, w, b, 1), *ops.linear_pre_gelu(a, w, b), ops.linear_mul_dgelu(a, w, b, prev)]
+        if M % 64 == 0:
+            B, H = (M // 4096, 64) if M % 4096 == 0 else (M // 64, 8)
+            sc = (1.25 * (torch.arange(B) % 3 != 0).float()).cuda()
+            outs += [ops.linear_residual(a, w, b, x, sc, B, H, H), ops.linear_residual(a, w, b, x, sc, B, H, H, windowed=True, shift=4 if H > 8 else 0)]
+        if N % 96 == 0 and K == N // 3 and M % 64 == 0:
+            outs += list(ops.qkv(a, w, b, K // 32))
+        return outs
+
+    monkeypatch.setenv("UF_GEMM_DMA", "0")
+    ref = run_all()
+    monkeypatch.setenv("UF_GEMM_DMA", "1")
+    got = run_all()
+    torch.cuda.synchronize()
+    for i, (g, r) in enumerate(zip(got, ref)):
+        assert torch.equal(g, r), f"output {i} of {M}x{N}x{K} differs between the DMA and the register-staged path: max abs {(g.float() - r.float()).abs().max().item():.3e}"
+    check(f"dma_linear_{M}x{N}x{K}", got[0], a.float().cpu() @ w.float().cpu().t() + b.cpu(), dtype)
+
+
 @pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (64, 2), (128, 4), (256, 8), (512, 16)])
 def test_ln_fused_projections(ops, dtype, C, heads):

@@ -884,6 +884,155 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad2_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight gradient, third version (round 4): linear_wgrad2 with the token tiles staged by LDS-DMA and 64-token steps.
+//   * `buffer_load_dwordx4 ... lds` moves dY[64][128] and X[64][128] straight into LDS (8 instructions per wave and step, each 4 token
+//     rows x 256 bytes); the XOR placement of the 16-byte pieces that keeps the transposing reads conflict-free (wg2_off) is obtained by
+//     permuting WHICH global piece a lane fetches.  No staging registers, no ds_write pass; token rows past M and columns past N / K
+//     read zeros through the buffer descriptor.
+//   * 64 tokens per barrier (two 32-row sub-tiles per buffer, 64 KiB of LDS for the double buffer, two workgroups per CU): 32 MFMAs per
+//     wave between barriers instead of 16.
+// Measured as a prototype in round 3 (scripts/ubench_hip/wgrad_dma.hip, profiles/r03_wgrad_dma.txt): +23 % at dec1, +38 % at dec0 over
+// linear_wgrad2.  The bias-summing workgroups (first K tile column) read their dY pieces back from LDS, same thread -> row mapping and
+// the same token order as the register path.  Chunks are ranges of 64-token steps, partial tiles as before.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void linear_wgrad3_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ X, int ldx,
+                                                               float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K, int S) {
+    constexpr int TOK = 64, TB = TOK * 256;                  // tokens per step, bytes of one operand tile
+    __shared__ __attribute__((aligned(1024))) char Ys[2][TB];
+    __shared__ __attribute__((aligned(1024))) char Xs[2][TB];
+    __shared__ float Bs[16][128 + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k_tiles = (K + 127) / 128, tiles = ((N + 127) / 128) * k_tiles;
+    const int xcd = (int)blockIdx.x & 7, seq = (int)blockIdx.x >> 3;      // XCD x walks chunks x, x + 8, ...: see linear_wgrad2_kernel
+    const int tile = seq % tiles, chunk = (seq / tiles) * 8 + xcd;
+    if (chunk >= S) return;
+    const int n0 = (tile / k_tiles) * 128, k0 = (tile % k_tiles) * 128;
+    const int wn = wave >> 1, wk = wave & 1;
+    const bool do_bias = (tile % k_tiles) == 0;
+    const int steps_all = (M + TOK - 1) / TOK;
+    const int s0 = (int)((long long)steps_all * chunk / S), s1 = (int)((long long)steps_all * (chunk + 1) / S);
+
+    const unsigned ybase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&Ys[0][0];
+    const unsigned xbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&Xs[0][0];
+    const unsigned long long ya = (unsigned long long)(uintptr_t)dY, xa = (unsigned long long)(uintptr_t)X;
+    const u32x4 rsy = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ya), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ya >> 32)) & 0xffffu,
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(M - 1) * (unsigned)ldy + (unsigned)N) * 2u)), 0x00020000u};
+    const u32x4 rsx = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32)) & 0xffffu,
+                       (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(M - 1) * (unsigned)ldx + (unsigned)K) * 2u)), 0x00020000u};
+    // wave w moves rows [16 w, 16 w + 16) of both tiles: instruction q = 4 rows; lane l lands at row 4 q + l / 16, position l % 16 and
+    // fetches piece (l % 16) ^ (rho(row % 32) << 1), rho as in wg2_off
+    unsigned voy[4], vox[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave * 4 + q) * 4 + (lane >> 4), r32 = row & 31;
+        const int rho = (r32 & 3) | (((r32 >> 3) & 1) << 2);
+        const int pc = (lane & 15) ^ (rho << 1);
+        voy[q] = (n0 + pc * 8 < N) ? ((unsigned)row * (unsigned)ldy + (unsigned)(n0 + pc * 8)) * 2u : 0xffffff00u;
+        vox[q] = (k0 + pc * 8 < K) ? ((unsigned)row * (unsigned)ldx + (unsigned)(k0 + pc * 8)) * 2u : 0xffffff00u;
+    }
+    auto dma_step = [&](int s, int buf) {
+        const unsigned sy = (unsigned)s * (unsigned)(TOK * 2) * (unsigned)ldy, sx = (unsigned)s * (unsigned)(TOK * 2) * (unsigned)ldx;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned rb = (unsigned)((wave * 4 + q) * 4) * 256u;
+            dma_buffer_to_lds(rsy, voy[q], sy, ybase + (unsigned)buf * TB + rb);
+            dma_buffer_to_lds(rsx, vox[q], sx, xbase + (unsigned)buf * TB + rb);
+        }
+    };
+    // bias sums (first K tile column only): the thread that staged piece pseg of rows prow + 16 q in the register path reads them back
+    const int prow = tid >> 4, pseg = tid & 15;
+    float bsum[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int trow = 8 * fg + (fr >> 2);
+    unsigned yaddr[4], xaddr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        yaddr[i] = ybase + wg2_off(trow, (wn * 64 + i * 16) / 4 + (fr & 3));
+        xaddr[i] = xbase + wg2_off(trow, (wk * 64 + i * 16) / 4 + (fr & 3));
+    }
+    if (s0 < s1) { dma_step(s0, 0); wait_dma<0>(); }
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        if (s + 1 < s1) dma_step(s + 1, buf ^ 1);           // the other buffer: last read in step s-1, all waves passed the barrier since
+        __builtin_amdgcn_sched_barrier(0);
+        if (do_bias) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = prow + 16 * q;
+                const u32x4 zy = *reinterpret_cast<const u32x4*>(Ys[buf] + (row >> 5) * 8192 + wg2_off(row & 31, pseg * 2));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float lo, hi; unpack2<T>(zy[e], lo, hi); bsum[2 * e] += lo; bsum[2 * e + 1] += hi; }
+            }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            u32x2 y0[4], y1[4], x0[4], x1[4];
+            const unsigned bo = (unsigned)buf * (unsigned)TB + (unsigned)sub * 8192u;
+            const unsigned ya0 = yaddr[0] + bo, ya1 = yaddr[1] + bo, ya2 = yaddr[2] + bo, ya3 = yaddr[3] + bo;
+            const unsigned xa0 = xaddr[0] + bo, xa1 = xaddr[1] + bo, xa2 = xaddr[2] + bo, xa3 = xaddr[3] + bo;
+            asm volatile(
+                "ds_read_b64_tr_b16 %0, %16\n\tds_read_b64_tr_b16 %1, %16 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %2, %17\n\tds_read_b64_tr_b16 %3, %17 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %4, %18\n\tds_read_b64_tr_b16 %5, %18 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %6, %19\n\tds_read_b64_tr_b16 %7, %19 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %8, %20\n\tds_read_b64_tr_b16 %9, %20 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %10, %21\n\tds_read_b64_tr_b16 %11, %21 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %12, %22\n\tds_read_b64_tr_b16 %13, %22 offset:1024\n\t"
+                "ds_read_b64_tr_b16 %14, %23\n\tds_read_b64_tr_b16 %15, %23 offset:1024\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                : "=&v"(y0[0]), "=&v"(y1[0]), "=&v"(y0[1]), "=&v"(y1[1]), "=&v"(y0[2]), "=&v"(y1[2]), "=&v"(y0[3]), "=&v"(y1[3]),
+                  "=&v"(x0[0]), "=&v"(x1[0]), "=&v"(x0[1]), "=&v"(x1[1]), "=&v"(x0[2]), "=&v"(x1[2]), "=&v"(x0[3]), "=&v"(x1[3])
+                : "v"(ya0), "v"(ya1), "v"(ya2), "v"(ya3), "v"(xa0), "v"(xa1), "v"(xa2), "v"(xa3)
+                : "memory");
+            Frag<T> a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i].v = u32x4{y0[i][0], y0[i][1], y1[i][0], y1[i][1]};
+                b[i].v = u32x4{x0[i][0], x0[i][1], x1[i][0], x1[i][1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][j], a[i], b[j]);
+        }
+        if (s + 1 < s1) wait_dma<0>();
+        __syncthreads();
+    }
+    float* wp = ws_w + (size_t)chunk * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + fg * 4 + r, k = k0 + wk * 64 + j * 16 + fr;
+                if (n < N && k < K) wp[(size_t)n * K + k] = acc[i][j][r];
+            }
+    if (do_bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) Bs[prow][pseg * 8 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += Bs[r][tid];
+            ws_b[(size_t)chunk * N + n0 + tid] = t;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Window attention backward (WindowAttention.forward, model.py:494-519, without the projections):
 //   P = softmax(q k^T + bias + mask);   dV = P^T dO;   dP = dO V^T;   dS = P o (dP - rowsum(dP o P));
 //   dq = dS k;   dk = dS^T q;   dbias[h] = sum over windows of dS        (q is the SCALED query the forward stores)
@@ -1304,7 +1453,13 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
         ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
         static const int xcd_map = !(getenv("UF_WGRAD_XCD") && atoi(getenv("UF_WGRAD_XCD")) == 0);          // 0: chunk-major order (A/B)
         const dim3 grid2((unsigned)(grid.x * (xcd_map ? (S + 7) / 8 * 8 : S)));
-        if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid2, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
+        // third version (LDS-DMA staging, 64-token steps) where both operands are addressable with 32-bit byte offsets; UF_WGRAD_DMA=0: second version
+        const char* e3 = getenv("UF_WGRAD_DMA");
+        const bool v3 = v2 && !(e3 && e3[0] == '0') && M >= 256 && (long long)M * ldy * 2 < 0xffffff00LL && (long long)M * ldx * 2 < 0xffffff00LL;
+        const dim3 grid3((unsigned)(grid.x * ((S + 7) / 8 * 8)));
+        if (v3 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad3_kernel<bf16>, grid3, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S);
+        else if (v3) hipLaunchKernelGGL(linear_wgrad3_kernel<f16>, grid3, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S);
+        else if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid2, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
         else if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel<f16>, grid2, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
         else UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(linear_wgrad_kernel<TT>, grid, dim3(256), 0, st, (const TT*)dY, ldy, (const TT*)X, ldx, ws_w, ws_b, M, N, K));
     }

@@ -231,6 +231,29 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
+// ---- LDS-DMA helpers (gfx950 `buffer_load_dwordx4 ... lds` / `global_load_lds_dwordx4`) ---------------------------------
+// The halo tile and the tap table of a chunk go HBM/L2 -> LDS without passing through registers.  They are written as
+// inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front
+// of the next ds_read, which would serialise the stencil behind its own prefetch; an asm statement is invisible to that
+// pass, the waits are counted by hand below (one `s_waitcnt vmcnt(N)` per iteration, then the workgroup barrier).
+// Destination: LDS byte address M0 + lane * 16 (wave-uniform base, lane-linear image); source: per-lane.  M0 is saved and
+// restored inside the statement (the compiler owns it).  The leading s_nop covers the SGPR-written-by-VALU
+// (v_readfirstlane) -> VMEM-descriptor hazard, the one after s_mov the M0 -> LDS-DMA hazard.
+__device__ __forceinline__ void dma_buffer_to_lds(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);   // wave-uniform by contract; makes it provably scalar for the "s" constraint
+    soff = (unsigned)__builtin_amdgcn_readfirstlane((int)soff);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dma_global_to_lds(const void* src, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_addr);
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(src) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
 // 8 operand elements of type T (one MFMA k-slot group per lane)
 template <typename T> struct Frag;
 template <> struct Frag<bf16> {

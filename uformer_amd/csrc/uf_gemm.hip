@@ -7,9 +7,17 @@
 // epilogue (bias / GELU / residual / window_reverse scatter / QKV split / deconv scatter)
 // works on 8-16 contiguous bytes per lane.
 //
-// Block tile 128(m) x BN(n), 4 wave64s, K tile of 128 bytes per row (64 bf16 / 32 f32),
-// double-buffered LDS with 16-byte row padding, register-staged global->LDS copies issued
-// before the MFMAs of the current tile (T14 of the CDNA guide), one barrier per K tile.
+// Block tile 128(m) x BN(n), 4 wave64s, K tile of 128 bytes per row (64 bf16 / 32 f32), double-buffered LDS, one barrier per K tile.
+// Two staging paths:
+//   * register-staged (every loader, every type): global_load_dwordx4 -> VGPRs -> ds_write_b128 into rows padded to 144 bytes, the
+//     global loads of tile t+1 issued before the MFMAs of tile t (T14 of the CDNA guide);
+//   * LDS-DMA (round 4; plain loader, 2-byte types, K a multiple of 64 and >= 2 tiles): `buffer_load_dwordx4 ... lds` straight into
+//     UNPADDED 128-byte rows; the bank-conflict-free placement (16-byte chunk c of row r at position c ^ (r & 7)) is obtained by
+//     permuting WHICH global chunk a lane fetches, not where it lands, and the fragment reads apply the same XOR.  No staging
+//     registers, no ds_write pass (per K tile a workgroup spent ~420 LDS-array cycles on ds_write_b128 next to 256 on fragment
+//     reads): measured as a prototype in round 3 (scripts/ubench_hip/gemm_dma.hip, profiles/r03_gemm_dma.txt) at +10...+34 % on the
+//     K-heavy shapes.  Rows past M / N read zeros through the buffer descriptor's bounds check.  Same MFMAs on the same operands in
+//     the same order: bit-identical results to the register path (tests/test_gpu_ops.py::test_gemm_dma_bit_identical).
 #include "uf_internal.h"
 
 namespace uf {
@@ -17,7 +25,7 @@ namespace uf {
 namespace {
 
 constexpr int BM = 128;
-constexpr int ROWB = 128 + 16;  // bytes per LDS row: 128 B of K + 16 B pad
+constexpr int ROWB_PAD = 128 + 16;  // bytes per LDS row of the register-staged path: 128 B of K + 16 B pad
 
 // One 16-byte chunk of the activation tile in flight.  issue() is an UNCONDITIONAL global load from
 // a clamped address (a bounds-guarded load makes hipcc emit an exec-masked branch with a vmcnt(0)
@@ -118,7 +126,20 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
     }
 }
 
-template <typename T, int BN, int WGM, int WGN, int AL, int EP>
+// dynamic LDS of a launch: two K-tile buffers, or the epilogue's staging area where that is larger (the f32 residual staging of the
+// unpadded DMA buffers: 68 KiB at BN = 128 -- still two workgroups per CU)
+template <typename T, int BN, int WGM, int WGN, int EP, bool DMA>
+constexpr int gemm_smem_bytes() {
+    constexpr int two = 2 * (BM + BN) * (DMA ? 128 : ROWB_PAD);
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int stgf = (EP == E_RES || EP == E_RES_WINREV) ? 4 * WTM * (WTN * 4 + 16) : 0;
+    constexpr int a = WTM * (WTN * (int)sizeof(T) + 16), b = WTN * (WTM * (int)sizeof(T) + 16);
+    constexpr int stg = (EP == E_STORE_T || EP == E_STORE_T_GELU || EP == E_QKV || EP == E_STORE_T_PRE_GELU || EP == E_STORE_T_MUL_DGELU) ? 4 * (a > b ? a : b) : 0;
+    constexpr int need = stgf > stg ? stgf : stg;
+    return two > need ? two : need;
+}
+
+template <typename T, int BN, int WGM, int WGN, int AL, int EP, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int EPC = 16 / sizeof(T);  // elements per 16-byte chunk
     constexpr int BK = 8 * EPC;          // elements per 128-byte K row
@@ -126,7 +147,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;
     constexpr int A_CH = BM / 32, W_CH = BN / 32;  // 16-byte chunks staged per thread
     static_assert(WGM * WGN == 4, "4 waves");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(!DMA || (sizeof(T) == 2 && AL == A_PLAIN), "LDS-DMA staging: plain loader, 2-byte operand types");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int ROWB = DMA ? 128 : ROWB_PAD;       // LDS row stride of a K tile
     constexpr int BUF_BYTES = (BM + BN) * ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,23 +194,66 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         for (int i = 0; i < W_CH; ++i) *reinterpret_cast<u32x4*>(Ws + (crow + 32 * i) * ROWB + ccol * 16) = rw[i].finish();
     };
 
-    g_load(0);
-    s_store(0);
+    // LDS-DMA staging: wave w moves rows [32 w, 32 w + 32) of the activation tile (4 instructions of 8 rows x 128 bytes) and rows
+    // [BN/4 w, ..) of the weight tile; lane l of an instruction lands at row 8 q + l / 8, position l % 8 and therefore fetches chunk
+    // (l % 8) ^ (row % 8).  Buffer descriptors bound both operands: rows past M / N read zeros.
+    u32x4 rsa = {0, 0, 0, 0}, rsw = {0, 0, 0, 0};
+    unsigned voa[A_CH], vow[W_CH];
+    unsigned lds0 = 0;
+    if constexpr (DMA) {
+        lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+        const unsigned long long aa = (unsigned long long)(uintptr_t)p.A, wa = (unsigned long long)(uintptr_t)p.W;
+        rsa = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)aa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(aa >> 32)) & 0xffffu,
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(p.M - 1) * (unsigned)p.lda + (unsigned)p.K) * 2u)), 0x00020000u};
+        rsw = u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wa >> 32)) & 0xffffu,
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)p.N * (unsigned)p.K * 2u)), 0x00020000u};
+#pragma unroll
+        for (int q = 0; q < A_CH; ++q) {
+            const int r = wave * 32 + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            voa[q] = (m0 + r) < p.M ? ((unsigned)(m0 + r) * (unsigned)p.lda + (unsigned)c * 8u) * 2u : 0xffffff00u;
+        }
+#pragma unroll
+        for (int q = 0; q < W_CH; ++q) {
+            const int r = wave * (BN / 4) + q * 8 + (lane >> 3), c = (lane & 7) ^ (r & 7);
+            vow[q] = (n0 + r) < p.N ? ((unsigned)(n0 + r) * (unsigned)p.K + (unsigned)c * 8u) * 2u : 0xffffff00u;
+        }
+    }
+    auto dma_tile = [&](int t, int buf) {
+        const unsigned soff = (unsigned)t * 128u, base = lds0 + (unsigned)buf * BUF_BYTES;
+#pragma unroll
+        for (int q = 0; q < A_CH; ++q) dma_buffer_to_lds(rsa, voa[q], soff, base + (unsigned)(wave * 32 + q * 8) * 128u);
+#pragma unroll
+        for (int q = 0; q < W_CH; ++q) dma_buffer_to_lds(rsw, vow[q], soff, base + (unsigned)(BM * 128 + (wave * (BN / 4) + q * 8) * 128));
+    };
+
+    if constexpr (DMA) {
+        dma_tile(0, 0);
+        wait_dma<0>();
+    } else {
+        g_load(0);
+        s_store(0);
+    }
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nt) g_load(t + 1);
+        if (t + 1 < nt) {
+            if constexpr (DMA) dma_tile(t + 1, buf ^ 1);
+            else g_load(t + 1);
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep the next tile's global loads ABOVE this tile's MFMAs
-        const char* As = smem + buf * BUF_BYTES + (wm * TM * 16 + fr) * ROWB + fg * (8 * (int)sizeof(T));
-        const char* Ws = smem + buf * BUF_BYTES + BM * ROWB + (wn * TN * 16 + fr) * ROWB + fg * (8 * (int)sizeof(T));
+        const int ra0 = wm * TM * 16 + fr, rw0 = wn * TN * 16 + fr;    // first fragment rows of this lane (16 j / 16 i more per tile: same r & 7)
+        const char* As = smem + buf * BUF_BYTES + ra0 * ROWB + (DMA ? 0 : fg * (8 * (int)sizeof(T)));
+        const char* Ws = smem + buf * BUF_BYTES + BM * ROWB + rw0 * ROWB + (DMA ? 0 : fg * (8 * (int)sizeof(T)));
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) {
             Frag<T> af[TM], wf[TN];
+            // DMA path: chunk (4 ks + fg) of row R sits at position (4 ks + fg) ^ (R & 7)
+            const int ca = DMA ? (((ks * 4 + fg) ^ (ra0 & 7)) * 16) : ks * 64, cw = DMA ? (((ks * 4 + fg) ^ (rw0 & 7)) * 16) : ks * 64;
 #pragma unroll
-            for (int j = 0; j < TM; ++j) load_frag(af[j], reinterpret_cast<const T*>(As + j * 16 * ROWB + ks * 64));
+            for (int j = 0; j < TM; ++j) load_frag(af[j], reinterpret_cast<const T*>(As + j * 16 * ROWB + ca));
 #pragma unroll
-            for (int i = 0; i < TN; ++i) load_frag(wf[i], reinterpret_cast<const T*>(Ws + i * 16 * ROWB + ks * 64));
+            for (int i = 0; i < TN; ++i) load_frag(wf[i], reinterpret_cast<const T*>(Ws + i * 16 * ROWB + cw));
             // QKV: waves that own columns of the V third compute their tiles TRANSPOSED (activation as
             // the MFMA A operand): a lane then holds 4 consecutive TOKENS of one channel, which is
             // contiguous in the V^T layout the attention kernel reads.  Wave-uniform branch.
@@ -203,7 +269,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                     for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[i], af[j]);
             }
         }
-        if (t + 1 < nt) s_store(buf ^ 1);
+        if (t + 1 < nt) {
+            if constexpr (DMA) wait_dma<0>();
+            else s_store(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -216,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         constexpr int SROW = WTN * (int)sizeof(T) + 16;   // staged row stride, [m][n] orientation
         constexpr int SROWT = WTM * (int)sizeof(T) + 16;  // transposed [n][m] orientation (V^T)
         constexpr int STG = (WTM * SROW > WTN * SROWT) ? WTM * SROW : WTN * SROWT;
-        static_assert(4 * STG <= 2 * BUF_BYTES, "staging does not fit the main-loop LDS");
-        static_assert(sizeof(T) != 2 || 4 * STG <= BUF_BYTES, "2-byte types: the staging must fit ONE buffer (single-buffer launches when K is one tile)");
+        static_assert(4 * STG <= gemm_smem_bytes<T, BN, WGM, WGN, EP, DMA>(), "staging does not fit the kernel's LDS");
+        static_assert(DMA || sizeof(T) != 2 || 4 * STG <= BUF_BYTES, "2-byte types: the staging must fit ONE buffer (single-buffer launches when K is one tile)");
         char* stg = smem + wave * STG;
         const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
         const int C = p.heads * p.hd;
@@ -318,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         constexpr int WTM = TM * 16, WTN = TN * 16;
         constexpr int SROWF = WTN * 4 + 16;
         constexpr int STGF = WTM * SROWF;
-        static_assert(4 * STGF <= 2 * BUF_BYTES, "f32 staging does not fit the main-loop LDS");
+        static_assert(4 * STGF <= gemm_smem_bytes<T, BN, WGM, WGN, EP, DMA>(), "f32 staging does not fit the kernel's LDS");
         char* stg = smem + wave * STGF;
         const int mw0 = m0 + wm * WTM, nw0 = n0 + wn * WTN;
 #pragma unroll
@@ -369,10 +438,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     }
 }
 
-template <typename T, int BN, int WGM, int WGN, int AL, int EP>
-int launch_cfg(const GemmParams& p, hipStream_t stream) {
-    constexpr int smem2 = 2 * (BM + BN) * ROWB;
-    auto kern = gemm_kernel<T, BN, WGM, WGN, AL, EP>;
+template <typename T, int BN, int WGM, int WGN, int AL, int EP, bool DMA>
+int launch_kern(const GemmParams& p, hipStream_t stream) {
+    constexpr int smem2 = gemm_smem_bytes<T, BN, WGM, WGN, EP, DMA>();
+    auto kern = gemm_kernel<T, BN, WGM, WGN, AL, EP, DMA>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem2, lds_done, "gemm")) return rc;
     // K within ONE tile (K <= 64 for the 2-byte types: every projection of the 32- and 64-channel stages, the ones with the most tokens):
@@ -381,12 +450,12 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
     // buffer; the f32 one and the f32 staging of the residual stores do not.)  UF_GEMM_LDS2=1 keeps both buffers, for A/B runs.
     static const bool lds2 = getenv("UF_GEMM_LDS2") != nullptr;
     constexpr int BKE = 8 * (16 / (int)sizeof(T));
-    const int smem = (sizeof(T) == 2 && EP != E_RES && EP != E_RES_WINREV && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;   // (the f32 staging of the residual stores needs both)
+    const int smem = (!DMA && sizeof(T) == 2 && EP != E_RES && EP != E_RES_WINREV && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;   // (the f32 staging of the residual stores needs both)
     const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d %dx%dx%d", TypeName<T>::s, BN, AL, EP, p.M, p.N, p.K);
+        snprintf(name, sizeof(name), "gemm_%s_bn%d_a%d_e%d%s %dx%dx%d", TypeName<T>::s, BN, AL, EP, DMA ? "_dma" : "", p.M, p.N, p.K);
     const double sz = sizeof(T), mn = (double)p.M * p.N, mk = (double)p.M * p.K;
     const double a_bytes = AL == A_PLAIN ? mk * sz : (AL == A_FROM_R ? mk * 4 : mk);  // conv-down reads each input once
     const double o_bytes = (EP == E_RES || EP == E_RES_WINREV) ? mn * 8 : ((EP == E_STORE_R || EP == E_UPSAMPLE) ? mn * 4 : mn * sz);
@@ -395,6 +464,20 @@ int launch_cfg(const GemmParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(kern, grid, dim3(256), smem, stream, p);
     }
     return check_launch("gemm");
+}
+
+// LDS-DMA staging where it applies (see the file comment): plain loader, 2-byte type, K a whole number (>= UF_GEMM_DMA_MINK / 64) of
+// 64-element tiles, both operands addressable with 32-bit byte offsets.  UF_GEMM_DMA=0 switches it off (A/B runs, bit-identity test).
+template <typename T, int BN, int WGM, int WGN, int AL, int EP>
+int launch_cfg(const GemmParams& p, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2 && AL == A_PLAIN) {
+        static const int mink = getenv("UF_GEMM_DMA_MINK") ? atoi(getenv("UF_GEMM_DMA_MINK")) : 128;
+        const char* e = getenv("UF_GEMM_DMA");      // read per call: the bit-identity test flips it inside one process
+        const bool on = !(e && e[0] == '0');
+        if (on && p.K % 64 == 0 && p.K >= mink && p.K >= 128 && (long long)p.M * p.lda * 2 < 0xffffff00LL && (long long)p.N * p.K * 2 < 0xffffff00LL)
+            return launch_kern<T, BN, WGM, WGN, AL, EP, true>(p, stream);
+    }
+    return launch_kern<T, BN, WGM, WGN, AL, EP, false>(p, stream);
 }
 
 template <typename T, int AL, int EP>

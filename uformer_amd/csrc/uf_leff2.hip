@@ -42,9 +42,12 @@ constexpr int KCW = 64;  // hidden channels one producer group (4 waves) convolv
 //      written to the operand tile of linear2 exactly as before.
 //   2  the same with every tap split into hi + lo parts of the operand type (9 k-steps: slots = {hi, lo} x 16 channels): products of
 //      2-byte operands are exact in the f32 accumulator, so the taps count with 16 (bf16) / 22 (f16) mantissa bits -- the f32 taps of
-//      the VALU form to 2^-17; only the summation order differs.  Default: the result stays inside the f32-tap error budget.
+//      the VALU form to 2^-17; only the summation order differs.
+// Measured (profiles/r04_run1.txt, same box, two interleaved runs): leff2 per step 2.948 ms (0) / 2.652 (1) / 3.097 (2); Uformer-B f16 error vs the
+// oracle 2.95e-4 / 2.72e-4 / 2.72e-4, bf16 1.89e-3 / 2.06e-3 / 1.92e-3.  Default 1: the split form's four extra k-steps and its per-tap
+// hi / lo arithmetic cost more issue slots than the VALU stencil it replaces.
 #ifndef UF_MCONV
-#define UF_MCONV 2
+#define UF_MCONV 1
 #endif
 template <typename T> __device__ __forceinline__ unsigned cvt16(float f);
 template <> __device__ __forceinline__ unsigned cvt16<bf16>(float f) { return f2bf(f); }
@@ -69,26 +72,6 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-// ---- LDS-DMA helpers (gfx950 `buffer_load_dwordx4 ... lds` / `global_load_lds_dwordx4`) ---------------------------------
-// The halo tile and the tap table of a chunk go HBM/L2 -> LDS without passing through registers.  They are written as
-// inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front
-// of the next ds_read, which would serialise the stencil behind its own prefetch; an asm statement is invisible to that
-// pass, the waits are counted by hand below (one `s_waitcnt vmcnt(N)` per iteration, then the workgroup barrier).
-// Destination: LDS byte address M0 + lane * 16 (wave-uniform base, lane-linear image); source: per-lane.  M0 is saved and
-// restored inside the statement (the compiler owns it).  The leading s_nop covers the SGPR-written-by-VALU
-// (v_readfirstlane) -> VMEM-descriptor hazard, the one after s_mov the M0 -> LDS-DMA hazard.
-__device__ __forceinline__ void dma_buffer_to_lds(u32x4 rsrc, unsigned voff, unsigned soff, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
-}
-__device__ __forceinline__ void dma_global_to_lds(const void* src, unsigned lds_addr) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_addr), "v"(src) : "memory");
-}
-template <int N> __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-
 // XCD-aware workgroup -> tile order: consecutive workgroup ids go to different XCDs (id % 8, MI355X_MICROARCH.md), so give
 // every XCD one contiguous run of tiles (whole image rows / images): the halo pixels that neighbouring tiles share are then
 // served by that XCD's L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
@@ -105,10 +88,12 @@ __device__ __forceinline__ int xcd_tile(int bid, int n) {
 // (<= 256 tiles, or C = 512 whose consumers need the registers): two stencil waves per SIMD hide each other's LDS latency.
 // Halo / tap tiles: NBUF-deep ring in LDS filled by DMA NBUF-1 intervals ahead; operand tile: double buffered; one barrier
 // per interval.
-template <typename T, int C, int NPG, int NC, int NBUF, int WPS>
-__global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const Leff2Params p) {
-    constexpr int NP = 4 * NPG;                   // producer waves
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4>
+__global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const Leff2Params p) {
+    constexpr int NP = PW * NPG;                  // producer waves: PW (4 or 8) per 64-channel group of the interval
     constexpr int MC = sizeof(T) == 2 ? UF_MCONV : 0;   // depthwise 3x3 on the MFMA (2-byte operand types), see UF_MCONV
+    static_assert(PW == 4 || (PW == 8 && MC != 0), "8 producer waves per group: MFMA stencil only (two pixel tiles per wave)");
+    constexpr int PTW = 16 / PW;                  // pixel tiles (16 pixels) per producer wave
     constexpr int SR = 2;                         // rows of the column strip one producer thread convolves
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
@@ -194,12 +179,12 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                 }
             }
         };
-        const int grp = wave >> 2;                              // producer group
-        const int gt = tid & 255;                               // thread index within the group
+        const int grp = wave / PW;                              // producer group
+        const int gt = tid & 255;                               // thread index within the group (VALU stencil)
         const int cvec = gt & 7, sx = (gt >> 3) & 7, sy0 = (gt >> 6) * SR;
         // MFMA stencil: the wave's 16-channel group, the lane's non-zero slot of the block-diagonal weight fragments, and the byte offsets
         // of its B fragments (pixel tile 0; tile pt adds two halo rows) per k-step
-        const int gq = wave & 3;
+        const int gq = wave & 3, pt0 = ((wave % PW) >> 2) * PTW;   // 16-channel group, first pixel tile
         const unsigned hshift = (fr & 1) * 16;
         unsigned msk[4];
 #pragma unroll
@@ -246,22 +231,23 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                         af[ks].v = u32x4{sh & msk[0], sh & msk[1], sh & msk[2], sh & msk[3]};
                     }
                     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(Wl + 9 * KC + gq * 16 + fg * 4);
-                    f32x4 cacc[4];
+                    f32x4 cacc[PTW];
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) cacc[pt] = bias4;
+                    for (int pt = 0; pt < PTW; ++pt) cacc[pt] = bias4;
+                    const char* Hp = Hs + pt0 * (2 * HW_ * PS);
 #pragma unroll
                     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-                        for (int pt = 0; pt < 4; ++pt) {
+                        for (int pt = 0; pt < PTW; ++pt) {
                             Frag<T> bf;
-                            bf.v = *reinterpret_cast<const u32x4*>(Hs + boff[ks] + pt * (2 * HW_ * PS));
+                            bf.v = *reinterpret_cast<const u32x4*>(Hp + boff[ks] + pt * (2 * HW_ * PS));
                             mma16(cacc[pt], af[ks], bf);                  // weights as A: lane = pixel fr, channels 4 fg .. 4 fg + 3
                         }
                     }
 #pragma unroll
-                    for (int pt = 0; pt < 4; ++pt) {
+                    for (int pt = 0; pt < PTW; ++pt) {
                         gelu4<T>(cacc[pt]);
-                        store4(reinterpret_cast<T*>(At + (pt * 16 + fr) * SAT) + gq * 16 + fg * 4, cacc[pt]);
+                        store4(reinterpret_cast<T*>(At + ((pt0 + pt) * 16 + fr) * SAT) + gq * 16 + fg * 4, cacc[pt]);
                     }
                 } else {
                 float o[SR][8];
@@ -345,6 +331,7 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
     // intervals, so their L2 round trip hides under the wait for the stencil
     w2_issue(0);
     lds_barrier();                                         // B0
+    unsigned long long ctw = 0, ctbar = 0, ct0 = __builtin_readcyclecounter(), ct1;
 #pragma unroll 1
     for (int j = 0; j <= NIT; ++j) {
         if (j >= 1) {
@@ -370,8 +357,11 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        ct1 = __builtin_readcyclecounter(); ctw += ct1 - ct0; ct0 = ct1;
         lds_barrier();
+        ct1 = __builtin_readcyclecounter(); ctbar += ct1 - ct0; ct0 = ct1;
     }
+    if (p.tbuf && lane == 0 && (bt & 63) == 0) { p.tbuf[((bt >> 6) * 16 + wave) * 4] = ctw; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 1] = ctbar; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 2] = 0; }
 
     // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
     const float dscale = p.drop ? p.drop[b] : 1.0f;
@@ -394,21 +384,21 @@ __global__ __launch_bounds__((4 * NPG + NC) * 64, WPS) void leff2_kernel(const L
     }
 }
 
-template <typename T, int C, int NPG, int NC, int NBUF, int WPS>
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4>
 int launch_v(const Leff2Params& p, hipStream_t st) {
     constexpr int SZ = sizeof(T), KC = KCW * NPG;
     constexpr int HGB = (100 * KCW * SZ + 1023) / 1024 * 1024, TGB = (10 * KC * 4 + 1023) / 1024 * 1024;
     constexpr int smem = NBUF * (NPG * HGB + TGB) + 2 * 64 * (KC * SZ + 16) + 1024;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = leff2_kernel<T, C, NPG, NC, NBUF, WPS>;
+    auto kern = leff2_kernel<T, C, NPG, NC, NBUF, WPS, PW>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "leff2")) return rc;
     const long long M = (long long)p.B * p.H * p.W;
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", TypeName<T>::s, C, 4 * NPG, NC, M, C, 4 * C);
+    if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", TypeName<T>::s, C, PW * NPG, NC, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((4 * NPG + NC) * 64), smem, st, p);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((PW * NPG + NC) * 64), smem, st, p);
     }
     return check_launch("leff2");
 }
@@ -422,6 +412,16 @@ template <typename T, int C>
 int launch_c(const Leff2Params& p, hipStream_t st) {
     static const bool alt = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'a';
     const int tiles = p.B * (p.H / 8) * (p.W / 8);
+    if constexpr (sizeof(T) == 2 && UF_MCONV != 0 && C >= 32) {
+        // UF_LEFF2_VARIANT=p: 8 producer waves per 64-channel group (two pixel tiles each) -- a producer wave is bound by its own
+        // instruction issue (one VALU instruction per ~5.3 cycles per wave, scripts/ubench_hip/valu_rate.hip), half the chain per interval
+        static const bool pw8 = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'p';
+        if (pw8) {
+            if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st);
+            else if constexpr (C == 256) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st);
+            else return launch_v<T, C, 1, 8, 4, 4, 8>(p, st);
+        }
+    }
     if constexpr (sizeof(T) == 2) {
         if constexpr (C <= 64) return launch_v<T, C, 1, 4, 2, 6>(p, st);
         else if constexpr (C == 128) return alt ? launch_v<T, C, 1, 4, 3, 4>(p, st) : launch_v<T, C, 1, 4, 2, 6>(p, st);
