@@ -252,6 +252,35 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
     return out
 
 
+def p720_mode(args, dev, ud, dtype_name, steps=3, warmup=1):
+    """BASELINE configs[4]: ONE 1280x720 frame, padded to a 1280x1280 square as the reference's test script does (test/test_sidd.py:79-92,
+    expand2square to a multiple of 128), through Uformer-B at that resolution, cropped back -- uformer_amd.infer.restore, every step on the
+    native kernels.  Returns the ``modes.p720`` entry (synthetic frame resident in HBM; parity of this path: tests/test_gpu_model.py against
+    the reference fixture model_B_720p.npz)."""
+    from uformer_amd import infer, spec
+    cfg = spec.arch_config(args.arch, img_size=256)
+    sd = spec.synth_state_dict(cfg, 1234)
+    m = build_model(args, cfg, sd, dev, TORCH_DTYPE[dtype_name])
+    frame = spec.synth_input(1, 720, 1280, 4321).to(dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            y = infer.restore(m, frame)
+        torch.cuda.synchronize(); ud.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = infer.restore(m, frame)
+        torch.cuda.synchronize(); ud.barrier()
+        dt = ud.max_over_ranks(time.perf_counter() - t0, dev) / steps
+    assert torch.isfinite(y).all() and tuple(y.shape[-2:]) == (720, 1280)
+    flops = 2.0 * m.flops() * (1280 * 1280) / (256.0 * 256.0)      # the padded square is what runs
+    out = {"workload": "Uformer_B, one 1280x720 frame -> expand2square 1280x1280 -> forward -> crop (uformer_amd.infer.restore), synthetic frame resident in HBM",
+           "ms_per_frame": 1e3 * dt, "frames_per_s": 1.0 / dt, "steps": steps, "dtype": dtype_name,
+           "mfma_frac": flops / dt / 1e12 / MFMA_PEAK_TFLOPS[dtype_name]}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def build_model(args, cfg, sd, dev, cd):
     from uformer_amd import model as um
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
@@ -290,6 +319,7 @@ def main():
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-f32 mode")
     ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
     ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
+    ap.add_argument("--no-720p", action="store_true", help="skip modes.p720 (BASELINE configs[4]: one 1280x720 frame through expand2square -> 1280x1280)")
     ap.add_argument("--train-mode-multi", action="store_true", help="run modes.train under N > 1 too (gradient all-reduce over RCCL)")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=3)
@@ -333,6 +363,10 @@ def main():
     if not args.no_train_mode and args.arch == "Uformer_B" and (world == 1 or args.train_mode_multi):
         train_entry = train_mode(args, cfg, sd, dev, ud, args.train_dtype)
 
+    p720_entry = None
+    if not args.no_720p and args.arch == "Uformer_B" and args.img == 256:
+        p720_entry = p720_mode(args, dev, ud, args.dtype)
+
     out = None
     if rank == 0:
         value = images / elapsed
@@ -362,6 +396,8 @@ def main():
                                    "mfma_frac_whole_model": v2 * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[other]}
         if train_entry is not None:
             out["modes"]["train"] = train_entry
+        if p720_entry is not None:
+            out["modes"]["p720"] = p720_entry
         # ---- roofline of the dominant kernel: HIP events on the launch stream, per kernel class ----
         rows = kernel_breakdown(model, x, 3)
         total_ms = sum(r["ms"] for r in rows)
@@ -454,6 +490,32 @@ def main():
                         "method": f"oracle/bf16_budget.py (operand={op_}): the f32 oracle with ONE rounding point / approximation of the {op_} kernels switched on at a time",
                         "by_source": BB.error_budget(x1, sd, ref, img_size=c2.img_size, embed_dim=c2.embed_dim, depths=c2.depths, num_heads=c2.num_heads, dd_in=c2.dd_in,
                                                      operand=op_)}
+        # ---- compact scalar block, LAST in the line (a log tail keeps it): every headline number of the modes above
+        md = out["modes"]
+        sm = {"dtype": args.dtype, "img_s": round(value, 1), "ms_step": round(1e3 * elapsed / args.steps, 3), "mfma_frac_model": round(out["mfma_frac_whole_model"], 4),
+              "dom_kernel": out["roofline"]["kernel"], "dom_bound": out["roofline"]["bound"], "dom_frac": round(out["roofline"]["frac"], 4),
+              "dom_avg_us": round(1e3 * out["roofline"]["avg_launch_ms"], 1), "dom_traffic": out["roofline"]["traffic"],
+              "gpu_ms_step_kernels": round(out["roofline"]["gpu_ms_per_step_all_kernels"], 3)}
+        for mname in ("bf16", "f16", "f32"):
+            if mname in md:
+                sm[mname + "_img_s"] = round(md[mname]["images_per_s"], 1)
+                if "max_abs_err_vs_oracle" in md[mname]:
+                    sm[mname + "_err"] = float("%.3e" % md[mname]["max_abs_err_vs_oracle"])
+                    sm[mname + "_meets_1e-3"] = md[mname]["meets_1e-3"]
+        if "train" in md:
+            tr = md["train"]
+            sm.update({"train_img_s": round(tr["images_per_s"], 1), "train_ms_step": round(tr["ms_per_step"], 2), "train_dtype": tr["dtype"], "train_batch": tr["batch_per_gpu"],
+                       "train_mfma_frac": round(tr["mfma_frac_whole_step"], 4), "train_peak_mem_gb": round(tr["peak_mem_gb"], 1)})
+            if "roofline" in tr:
+                sm.update({"train_dom_kernel": tr["roofline"]["kernel"], "train_dom_bound": tr["roofline"]["bound"], "train_dom_frac": round(tr["roofline"]["frac"], 4),
+                           "train_dom_traffic": tr["roofline"].get("traffic")})
+            if "cpu_baseline" in tr:
+                sm["train_cpu_img_s"] = round(tr["cpu_baseline"]["value"], 3)
+        if "p720" in md:
+            sm.update({"p720_ms": round(md["p720"]["ms_per_frame"], 2), "p720_fps": round(md["p720"]["frames_per_s"], 1), "p720_mfma_frac": round(md["p720"]["mfma_frac"], 4)})
+        if "cpu_baseline" in out:
+            sm.update({"cpu_img_s": round(out["cpu_baseline"]["value"], 3), "cpu_cores": out["cpu_baseline"]["cores"], "cpu_kind": out["cpu_baseline"]["kind"]})
+        out["summary"] = sm
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

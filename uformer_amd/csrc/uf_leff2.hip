@@ -413,14 +413,17 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
     static const bool alt = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'a';
     const int tiles = p.B * (p.H / 8) * (p.W / 8);
     if constexpr (sizeof(T) == 2 && UF_MCONV != 0 && C >= 32) {
-        // UF_LEFF2_VARIANT=p: 8 producer waves per 64-channel group (two pixel tiles each) -- a producer wave is bound by its own
-        // instruction issue (one VALU instruction per ~5.3 cycles per wave, scripts/ubench_hip/valu_rate.hip), half the chain per interval
-        static const bool pw8 = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'p';
-        if (pw8) {
-            if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st);
-            else if constexpr (C == 256) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st);
-            else return launch_v<T, C, 1, 8, 4, 4, 8>(p, st);
-        }
+        // 8 producer waves per 64-channel group (two pixel tiles each) where the grid is at most one round of workgroups: a producer wave
+        // is a serial chain of LDS round trips (taps -> fragments -> halo reads -> MFMA -> GELU -> operand tile: ~2 K cycles per interval
+        // for ~250 instructions, scripts/ubench.py stamps2), so with nothing else resident on the CU shorter chains win -- enc2 (C = 128,
+        // 1024 tiles) 0.322 -> 0.307 ms per step, enc3 (C = 256, 256 tiles) 0.247 -> 0.234; with several rounds of workgroups the wider
+        // workgroups cost residency (dec1 0.631 -> 0.739, C <= 64 +4...9 %): profiles/r04_run2.txt.  UF_LEFF2_VARIANT=p forces it, =n never.
+        static const char* ev = getenv("UF_LEFF2_VARIANT");
+        const bool force = ev && ev[0] == 'p', never = ev && ev[0] == 'n';
+        if constexpr (C == 128) { if (!never && (force || tiles <= 1024)) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
+        else if constexpr (C == 256) { if (!never && (force || tiles <= 256)) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st); }
+        else if constexpr (C == 512) { if (force) return launch_v<T, C, 1, 8, 4, 4, 8>(p, st); }
+        else { if (force) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
     }
     if constexpr (sizeof(T) == 2) {
         if constexpr (C <= 64) return launch_v<T, C, 1, 4, 2, 6>(p, st);
