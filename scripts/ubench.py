@@ -230,3 +230,32 @@ def bench_census():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "census":
     bench_census()
+
+
+def bench_census_attn():
+    """Census of the fused attention-half kernel on the stage shapes: workgroups per CU, block life in ns (100 MHz wall clock) and in
+    s_memtime cycles -> the shader clock the kernel really ran at."""
+    from uformer_amd import _lib, model
+    lib = _lib.load()
+    for (B, H, C, heads) in ((16, 64, 256, 8), (16, 32, 512, 16), (16, 32, 256, 8), (16, 64, 128, 4), (16, 128, 128, 4), (16, 256, 64, 2), (16, 128, 64, 2), (16, 256, 32, 1)):
+        blk = model.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
+        bp = blk._pack(torch.bfloat16)
+        M = B * H * H
+        x = torch.randn(M, C, device="cuda")
+        nbytes = lib.uf_block_workspace_bytes(M, C, 1)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        tb = torch.zeros(TBUF_ELEMS, dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+        t_us = timeit(lambda: lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st), n=10, warm=1)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(tb.data_ptr())
+        lib.uf_lewin_attn_fwd(bp, x.data_ptr(), C, B, H, H, C, None, 0, 1, ws.data_ptr(), nbytes, st)
+        torch.cuda.synchronize()
+        lib.uf_debug_set_tbuf(None)
+        census_report(f"attn_block M={M} C={C} ({t_us:.1f} us)", tb, min(M // 64, 32768))
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "census2":
+    bench_census_attn()

@@ -376,6 +376,41 @@ def test_samplers_golden(golden, dtype):
     check("output_proj", op(t(g["xo"]).cuda()), t(g["yo"]), torch.float32)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 40, 72), (3, 8, 130), (1, 13, 70)])
+def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
+    """The LDS-staged stem / head kernels (round 4: input_proj2 with the image tile + weights in LDS, output_proj2 with the halo tile of
+    token rows fetched once by LDS-DMA) against the first global-load forms they replace: same products, same order of additions ->
+    bit-identical, including image borders and sizes that are not multiples of the tile; and against the oracle."""
+    gen = torch.Generator().manual_seed(B * 1000 + H + W)
+    img = torch.rand(B, 3, H, W, generator=gen).cuda()
+    for E in (16, 32):
+        w = (torch.randn(E, 3, 3, 3, generator=gen) * 0.2)
+        bias = torch.randn(E, generator=gen) * 0.1
+        from uformer_amd import packing
+        w27 = packing.pack_input_proj(w).cuda()
+        monkeypatch.setenv("UF_INPUT_PROJ_V1", "1")
+        ref = ops.input_proj(img, w27, bias.cuda())
+        monkeypatch.setenv("UF_INPUT_PROJ_V1", "0")
+        got = ops.input_proj(img, w27, bias.cuda())
+        assert torch.equal(got, ref), f"input_proj E={E}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
+        ora = O.input_proj(img.cpu(), {"input_proj.proj.0.weight": w, "input_proj.proj.0.bias": bias})
+        check(f"input_proj2_E{E}_{H}x{W}", got.reshape(B, H * W, E), ora, torch.float32)
+    for C2 in (16, 32, 64):
+        x = torch.randn(B * H * W, C2, generator=gen).cuda()
+        w = torch.randn(3, C2, 3, 3, generator=gen) * 0.1
+        bias = torch.randn(3, generator=gen) * 0.1
+        from uformer_amd import packing
+        wp = packing.pack_output_proj(w).cuda()
+        for add in (None, img):
+            monkeypatch.setenv("UF_OUTPUT_PROJ_V1", "1")
+            ref = ops.output_proj(x, wp, bias.cuda(), B, H, W, add)
+            monkeypatch.setenv("UF_OUTPUT_PROJ_V1", "0")
+            got = ops.output_proj(x, wp, bias.cuda(), B, H, W, add)
+            assert torch.equal(got, ref), f"output_proj C2={C2}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
+        ora = torch.nn.functional.conv2d(x.cpu().reshape(B, H, W, C2).permute(0, 3, 1, 2), w, bias, stride=1, padding=1) + img.cpu()    # OutputProj + global residual (model.py:828-836, :1305)
+        check(f"output_proj2_C{C2}_{H}x{W}", got, ora, torch.float32)
+
+
 @pytest.mark.parametrize("dtype", MODES)
 def test_samplers_oracle_bigger(dtype):
     """Downsample / Upsample at widths that cross GEMM tile edges (N=256/1024, K=2048/256)."""

@@ -254,6 +254,14 @@ __device__ __forceinline__ void dma_global_to_lds(const void* src, unsigned lds_
 }
 template <int N> __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// XCD-aware workgroup -> tile order: consecutive workgroup ids go to different XCDs (id % 8, MI355X_MICROARCH.md), so give
+// every XCD one contiguous run of tiles (whole image rows / images): the halo pixels that neighbouring tiles share are then
+// served by that XCD's L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_tile(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 // 8 operand elements of type T (one MFMA k-slot group per lane)
 template <typename T> struct Frag;
 template <> struct Frag<bf16> {

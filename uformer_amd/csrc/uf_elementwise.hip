@@ -369,6 +369,66 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// a12, second form (round 4): the same convolution with the image tile and the weights staged in LDS.  The first form issues 81 global
+// loads (54 of them 4-byte broadcast loads) per 432 FMAs and measured 1.1 TB/s of its 134 MB output (123 us at 16 x 256 x 256,
+// profiles/r03_kernels_hip_events.json) -- bound by its own load instructions, not by the store stream.  Here a workgroup owns 4 image
+// rows x TW pixels: the (4 + 2) x (TW + 2) x Cin input halo (zero-padded at the image border) and the 27 x E weights go to LDS once,
+// coalesced; a thread owns 4 output channels x a strip of 8 horizontally adjacent pixels and reads per (channel, row) its 10 input
+// values as three vector LDS reads and per tap one 16-byte weight vector: 54 LDS reads per 432 x 2 packed FMAs, no global load in the
+// loop.  The E/4 lanes of a pixel still write one contiguous token row.  Same products in the same order as the first form
+// (accumulation starts at the bias, channels outer, rows, then taps): bit-identical results (tests/test_gpu_ops.py).
+// ---------------------------------------------------------------------------------------
+template <int EG>                                   // lanes per pixel = E / 4 (8 for E = 32, 4 for E = 16)
+__global__ __launch_bounds__(256, 4) void input_proj2_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
+                                                          float* __restrict__ out, int ld_o, int B, int H, int W) {
+    constexpr int CIN = 3, E = EG * 4, SL = 8, NSTRIP = 64 / EG, TW = NSTRIP * SL, RS = TW + 4;     // row stride in floats (16-byte multiple; index j = pixel x0 - 1 + j)
+    __shared__ __attribute__((aligned(16))) float Is[CIN][6][RS];
+    __shared__ __attribute__((aligned(16))) float Ws[27 * E];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * 4, b = blockIdx.z;
+    for (int i = tid; i < CIN * 6 * (TW + 2); i += 256) {
+        const int j = i % (TW + 2), r = (i / (TW + 2)) % 6, ci = i / ((TW + 2) * 6);
+        const int ix = x0 - 1 + j, iy = y0 - 1 + r;
+        const bool ok = ix >= 0 && ix < W && iy >= 0 && iy < H;
+        const float v = img[(size_t)((b * CIN + ci) * H + (ok ? iy : 0)) * W + (ok ? ix : 0)];
+        Is[ci][r][j] = ok ? v : 0.0f;
+    }
+    for (int i = tid; i < 27 * E; i += 256) Ws[i] = w27[i];
+    __syncthreads();
+    const int e = (lane % EG) * 4, strip = lane / EG;
+    const int yh = y0 + wave, xs = x0 + strip * SL;
+    if (yh >= H || xs >= W) return;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + e);
+    f32x4 acc[SL];
+#pragma unroll
+    for (int q = 0; q < SL; ++q) acc[q] = bv;
+#pragma unroll 1
+    for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const float* row = &Is[ci][wave + ky][strip * SL];
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(row), a1 = *reinterpret_cast<const f32x4*>(row + 4);
+            const f32x2_t a2 = *reinterpret_cast<const f32x2_t*>(row + 8);
+            const float v[SL + 2] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1]};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&Ws[(ci * 9 + ky * 3 + kx) * E + e]);
+#pragma unroll
+                for (int q = 0; q < SL; ++q) acc[q] += v[q + kx] * wv;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SL; ++q) {
+        if (xs + q >= W) break;
+        f32x4 a = acc[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = a[i] >= 0.f ? a[i] : 0.01f * a[i];
+        *reinterpret_cast<f32x4*>(out + (size_t)((b * H + yh) * W + xs + q) * ld_o + e) = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // a14: OutputProj conv3x3(C2->3) (+ global residual), token rows -> NCHW image (model.py:869-890, :1305).
 // LPP = C2/4 lanes share a column strip of OP_R vertically adjacent pixels, each lane owning 4 input
 // channels; per kx the 9 weight vectors (3 ky x 3 outputs) are loaded once and the OP_R + 2 token rows of
@@ -438,6 +498,91 @@ __global__ __launch_bounds__(256) void output_proj_kernel(const float* __restric
             float v = (sub == 0 ? a[r][0] : (sub == 1 ? a[r][1] : a[r][2])) + bs;
             if (add_img) v += img[o];  // return x + y (model.py:1305)
             out[o] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// a14, second form (round 4): the same convolution with the (4 + 2) x (TW + 2) halo tile of token rows staged in LDS by LDS-DMA.  In the
+// first form the three column taps of a pixel are loaded by three different lane groups and the six rows of a strip feed four output rows:
+// every token row travels L2 -> L1 -> registers 4.5 times, and the kernel ran at 1.6-2.0 TB/s of its 268 MB input (168 us at 16 x 256 x 256).
+// Here a workgroup fetches its tile once (`buffer_load_dwordx4 ... lds`, zero padding = out-of-range buffer offsets), workgroups follow
+// the XCD-aware tile order of leff2 (neighbouring tiles share halo rows in one XCD's L2), and the products run from LDS: same
+// per-lane partial sums, the same DPP all-reduce, the same order of additions as the first form -- bit-identical results.
+// ---------------------------------------------------------------------------------------
+template <int LPP>
+__global__ __launch_bounds__(256) void output_proj2_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           const float* __restrict__ img, float* __restrict__ out, int B, int H, int W, int add_img, int tiles_x, int tiles_y) {
+    constexpr int C2 = LPP * 4, NCOL = 256 / LPP, NX = 2, TW = NX * NCOL, HW2 = TW + 2;
+    extern __shared__ __attribute__((aligned(1024))) char smem_op[];
+    float* tile = reinterpret_cast<float*>(smem_op);                 // [6][TW + 2][C2]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bt = xcd_tile(blockIdx.x, gridDim.x);
+    const int b = bt / (tiles_x * tiles_y), tr = bt - b * (tiles_x * tiles_y);
+    const int y0 = (tr / tiles_x) * OP_R, x0 = (tr % tiles_x) * TW;
+    {
+        const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem_op;
+        const unsigned long long xa = (unsigned long long)(uintptr_t)x;
+        const u32x4 rsrc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(xa >> 32)) & 0xffffu,
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)B * (unsigned)H * (unsigned)W * (unsigned)ld_x * 4u)), 0x00020000u};
+        constexpr int NPC = 6 * HW2 * LPP, NINS = (NPC + 63) / 64;
+#pragma unroll 1
+        for (int idx = wave; idx < NINS; idx += 4) {
+            const int q = idx * 64 + lane, hp = q / LPP, part = q - hp * LPP;
+            const int r = hp / HW2, c = hp - r * HW2;
+            const int iy = y0 - 1 + r, ix = x0 - 1 + c;
+            unsigned voff = 0xffffff00u;
+            if (hp < 6 * HW2 && iy >= 0 && iy < H && ix >= 0 && ix < W) voff = ((unsigned)((b * H + iy) * W + ix) * (unsigned)ld_x + (unsigned)part * 4u) * 4u;
+            dma_buffer_to_lds(rsrc, voff, 0u, lds0 + (unsigned)idx * 1024u);
+        }
+        wait_dma<0>();
+    }
+    __syncthreads();
+    const int sub = tid % LPP, col = tid / LPP;
+    const float* ws = w + sub * 4;
+    const float bs = bias[sub < 3 ? sub : 0];
+#pragma unroll 1
+    for (int j = 0; j < NX; ++j) {
+        f32x4 acc[OP_R][3];
+#pragma unroll
+        for (int r = 0; r < OP_R; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx) {                   // not unrolled: nine weight vectors live at a time (the compiler otherwise hoists all 27 out of the column loop)
+            f32x4 wk[3][3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wk[ky][c] = *reinterpret_cast<const f32x4*>(ws + (c * 9 + ky * 3 + kx) * C2);
+#pragma unroll
+            for (int hr = 0; hr < OP_R + 2; ++hr) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(tile + ((hr * HW2) + col + NCOL * j + kx) * C2 + sub * 4);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = hr - ky;
+                    if (r < 0 || r >= OP_R) continue;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) acc[r][c] += v * wk[ky][c];
+                }
+            }
+        }
+        float a[OP_R][3];
+#pragma unroll
+        for (int r = 0; r < OP_R; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[r][c] = allreduce<RedSum, LPP>((acc[r][c][0] + acc[r][c][1]) + (acc[r][c][2] + acc[r][c][3]));
+        const int xw = x0 + col + NCOL * j;
+        if (sub < 3 && xw < W) {
+#pragma unroll
+            for (int r = 0; r < OP_R; ++r) {
+                if (y0 + r >= H) break;
+                const size_t o = ((size_t)b * 3 + sub) * H * W + (size_t)(y0 + r) * W + xw;
+                float v = (sub == 0 ? a[r][0] : (sub == 1 ? a[r][1] : a[r][2])) + bs;
+                if (add_img) v += img[o];
+                out[o] = v;
+            }
         }
     }
 }
@@ -628,6 +773,13 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
     UF_REQUIRE(H <= 65535 && B <= 65535, UF_ERR_SHAPE, "uf_input_proj_fwd: H=%d B=%d exceed the launch grid", H, B);
     const unsigned nx = (unsigned)((W + IP_PX - 1) / IP_PX) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
+    const char* e1 = getenv("UF_INPUT_PROJ_V1");                           // A/B switch / bit-identity test: the first (global-load) form
+    const bool v1 = e1 && e1[0] != '0';
+    if (!v1 && Cin == 3 && (E == 32 || E == 16) && (H + 3) / 4 <= 65535) {
+        if (E == 32) hipLaunchKernelGGL(input_proj2_kernel<8>, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
+        else hipLaunchKernelGGL(input_proj2_kernel<4>, dim3((W + 127) / 128, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
+        return check_launch("input_proj");
+    }
     hipLaunchKernelGGL(input_proj_kernel, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
     return check_launch("input_proj");
 }
@@ -640,6 +792,27 @@ extern "C" int uf_output_proj_fwd(const float* x, int ld_x, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     const long long pix = (long long)B * H * W;
     ScopedTimer tm("output_proj", 54.0 * pix * C2, 4.0 * pix * (C2 + 6), st);
+    {   // second form (LDS-DMA staged halo tile) where the tile fits LDS and 32-bit byte offsets address the tensor; UF_OUTPUT_PROJ_V1=1: first form
+        const char* e1 = getenv("UF_OUTPUT_PROJ_V1");
+        const bool v1 = e1 && e1[0] != '0';
+        if (!v1 && (C2 == 16 || C2 == 32 || C2 == 64) && (long long)B * H * W * ld_x * 4 < 0xffffff00LL) {
+            const int lpp = C2 / 4, tw = 2 * (256 / lpp), tiles_x = (W + tw - 1) / tw, tiles_y = (H + OP_R - 1) / OP_R;
+            const int smem = 6 * (tw + 2) * C2 * 4;
+            const long long nt = (long long)tiles_x * tiles_y * B;
+            if (nt < 0x7fffffffLL) {
+#define UF_OP2(LPPV)                                                                                                                                  \
+                {                                                                                                                                     \
+                    auto kern = output_proj2_kernel<LPPV>;                                                                                            \
+                    static bool lds_done[64] = {};                                                                                                    \
+                    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "output_proj")) return rc;                  \
+                    hipLaunchKernelGGL(kern, dim3((unsigned)nt), dim3(256), smem, st, x, ld_x, w, bias, img, out, B, H, W, add_img, tiles_x, tiles_y); \
+                }
+                if (lpp == 4) UF_OP2(4) else if (lpp == 8) UF_OP2(8) else UF_OP2(16)
+#undef UF_OP2
+                return check_launch("output_proj");
+            }
+        }
+    }
 #define UF_OP_CASE(LPPV)                                                                                          \
     case LPPV * 4: {                                                                                              \
         const unsigned nx = (unsigned)W * LPPV;                                                                   \

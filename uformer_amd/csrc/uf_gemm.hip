@@ -161,7 +161,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     // affects speed, never results.
     const int n_tiles = (p.N + BN - 1) / BN;
     const int seq = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const int mt = (seq / n_tiles) * 8 + xcd;
+    // Downsample (im2col loader): output rows oy and oy + 1 share two of their four input rows, so NEIGHBOURING M tiles read the same
+    // tokens -- interleaved over the XCDs (mt % 8) each L2 fetched them for itself: 1.83-2.05 x the algorithmic HBM traffic
+    // (profiles/r03_pmc_traffic.json).  Every XCD therefore walks one CONTIGUOUS run of M tiles here.
+    const int mt = AL == A_CONV_DOWN ? xcd * ((int)gridDim.x / (8 * n_tiles)) + seq / n_tiles : (seq / n_tiles) * 8 + xcd;
     if (mt * BM >= p.M) return;
     const int m0 = mt * BM, n0 = (seq % n_tiles) * BN;
     const int wm = wave / WGN, wn = wave % WGN;

@@ -72,14 +72,6 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-// XCD-aware workgroup -> tile order: consecutive workgroup ids go to different XCDs (id % 8, MI355X_MICROARCH.md), so give
-// every XCD one contiguous run of tiles (whole image rows / images): the halo pixels that neighbouring tiles share are then
-// served by that XCD's L2 instead of being fetched from HBM once per XCD.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_tile(int bid, int n) {
-    const int q = n >> 3, r = n & 7, x = bid & 7, k = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
-
 // Wave-specialised kernel.  4*NPG PRODUCER waves (depthwise stencil + GELU on the VALU, and the LDS-DMA prefetch of the halo /
 // tap tiles) and NC CONSUMER waves (W2 fragments L2 -> registers, MFMAs, epilogue).  The hardware spreads the waves of a
 // workgroup over the 4 SIMDs, and the VALU and matrix pipes of a SIMD run concurrently for different waves, so the stencil
