@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""round 4 debugging aid: leff2 variants (8 producer waves forced / never) must agree bit for bit on the stage shapes"""
+import os, subprocess, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+if len(sys.argv) > 1:
+    from uformer_amd import ops
+    torch.manual_seed(0)
+    outs = []
+    for (B, H, C) in ((1, 64, 128), (16, 64, 128), (1, 128, 128), (1, 64, 256), (4, 32, 256), (16, 32, 256), (1, 32, 512), (2, 256, 64), (1, 256, 32)):
+        g = torch.Generator().manual_seed(B * 7 + H + C)
+        h1 = torch.randn(B, H, H, 4 * C, generator=g).to(torch.bfloat16).cuda()
+        w9 = (torch.randn(9, 4 * C, generator=g) * 0.2).cuda(); bd = (torch.randn(4 * C, generator=g) * 0.1).cuda()
+        w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).to(torch.bfloat16).cuda(); b2 = torch.randn(C, generator=g).cuda()
+        x = torch.randn(B * H * H, C, generator=g).cuda()
+        y1 = ops.dwconv_linear2(h1, w9, bd, w2, b2, x.clone())
+        y2 = ops.dwconv_linear2(h1, w9, bd, w2, b2, x.clone())
+        outs.append((B, H, C, y1.cpu(), bool(torch.equal(y1, y2))))
+    torch.save(outs, sys.argv[1])
+else:
+    for v in ("n", "p"):
+        subprocess.check_call([sys.executable, __file__, f"/tmp/leff2_{v}.pt"], env=dict(os.environ, UF_LEFF2_VARIANT=v))
+    a, b = torch.load("/tmp/leff2_n.pt"), torch.load("/tmp/leff2_p.pt")
+    for (B, H, C, ya, da), (_, _, _, yb, db) in zip(a, b):
+        d = (ya - yb).abs()
+        print(f"B={B} H={H} C={C}: never-vs-forced max abs diff {d.max().item():.3e} (nonzero {int((d > 0).sum())} of {d.numel()}), deterministic n={da} p={db}")

@@ -91,6 +91,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #endif
 template <int C> constexpr bool hoist_on() { return (C <= 128 && (UF_HOIST & 1)) || (C == 256 && (UF_HOIST & 2)) || (C == 512 && (UF_HOIST & 4)); }
 
+#ifndef UF_ATTN_LR_DEFAULT
+#define UF_ATTN_LR_DEFAULT 0
+#endif
 template <typename T> struct FragFromAcc {   // primary: the 2-byte operand types
     static __device__ __forceinline__ void make(Frag<T>& f, f32x4 a, f32x4 b) {
         f.v = u32x4{pack2<T>(a[0], a[1]), pack2<T>(a[2], a[3]), pack2<T>(b[0], b[1]), pack2<T>(b[2], b[3])};
@@ -115,20 +118,21 @@ template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // bala
 // permlane-widened direct 16-byte stores.  2-byte operand types only.
 // Fc1Walk::first(): the weight fragments of the wave's first unit (callable before the operand tile exists: UF_HOIST);
 // Fc1Walk::run(): the walk.
-template <typename T, int C, int WAVES>
+template <typename T, int C, int WAVES, int UW = 4>
 struct Fc1Walk {
-    static constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / 64;
-    const T* wrow[4];
-    Frag<T> wf[RING][4];
+    static_assert(UW == 4 || UW == 2, "units of 64 x 64 or 64 x 32");
+    static constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / (16 * UW);
+    const T* wrow[UW];
+    Frag<T> wf[RING][UW];
     const T* W1;
     int lane;
     __device__ __forceinline__ void wload(int ks, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+        for (int i = 0; i < UW; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
     }
     __device__ __forceinline__ void unit_prefetch(int u) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) wrow[i] = W1 + ((size_t)(u * 4 + i) * KS * 64 + lane) * 8;
+        for (int i = 0; i < UW; ++i) wrow[i] = W1 + ((size_t)(u * UW + i) * KS * 64 + lane) * 8;
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s)
             if (s < KS) wload(s, s);
@@ -148,10 +152,10 @@ struct Fc1Walk {
     if (WAVES == 8 && UF_FC1_OFFSET > 0 && wave >= 4) __builtin_amdgcn_s_sleep(UF_FC1_OFFSET * (C / 256) > 127 ? 127 : UF_FC1_OFFSET * (C / 256));   // as in phase 1
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
-        const int nbase = u * 64;
-        f32x4 acc[4][4];
+        const int nbase = u * 16 * UW;
+        f32x4 acc[UW][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < UW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         const char* arow = Xn + fr * SA + fg * 8 * SZ;
@@ -161,9 +165,9 @@ struct Fc1Walk {
             for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(arow + j * 16 * SA + ks * 32 * SZ));
         };
         aload(0, 0);
-        f32x4 bv[4];   // the unit's bias: requested here, consumed after the k-loop (was an exposed L2 round trip per unit)
+        f32x4 bv[UW];   // the unit's bias: requested here, consumed after the k-loop (was an exposed L2 round trip per unit)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(b1 + nbase + i * 16 + fg * 4);
+        for (int i = 0; i < UW; ++i) bv[i] = *reinterpret_cast<const f32x4*>(b1 + nbase + i * 16 + fg * 4);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if (ks + RING - 1 < KS) wload(ks + RING - 1, (ks + RING - 1) % RING);
@@ -171,7 +175,7 @@ struct Fc1Walk {
             __builtin_amdgcn_sched_barrier(0);
             UF_PRIO_UP();
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < UW; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mma16(acc[i][j], wf[ks % RING][i], af[ks & 1][j]);   // weight as A: lane = 4 channels of one token
             UF_PRIO_DN();
@@ -182,7 +186,7 @@ struct Fc1Walk {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
-            for (int ip = 0; ip < 4; ip += 2) {
+            for (int ip = 0; ip < UW; ip += 2) {
                 f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
                 gelu4<T>(va); gelu4<T>(vb);
                 const unsigned a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
@@ -203,8 +207,14 @@ struct NoWalk {   // f32 operands: phase 3 does not exist
     template <typename... A> __device__ __forceinline__ void run(A...) {}
 };
 
-template <typename T, int C, int NT>
-__global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2)) void attn_block_kernel(const AttnBlkParams p) {
+// LR = 1 (round 4, 2-byte operand types at C <= 128): the low-register form.  The q / k / v projections of a unit run ONE AFTER THE OTHER (k, v,
+// then q) through one flattened weight ring of two fragments per k-step instead of six, each projection's accumulators turn into operand
+// fragments before the next one starts, and phase 3 walks 64 x 32 units: 109 / 168 / 220 registers at C = 32 / 64 / 128 become
+// <= 96 / 128 / 168, i.e. 5 / 4 / 3 workgroups per CU instead of 4 / 3 / 2.  These widths are bound by how many independent windows a
+// CU holds (a wave issues one instruction per ~5.3 cycles and waits on LDS / L2 round trips between its phases).  Same
+// MFMAs on the same operands in the same order per accumulator: bit-identical results to LR = 0.
+template <typename T, int C, int NT, int LR = 0>
+__global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : ((sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2))) void attn_block_kernel(const AttnBlkParams p) {
     constexpr int SZ = sizeof(T);
     constexpr int WAVES = NT / 64;
     constexpr int HEADS = C / 32;
@@ -252,18 +262,26 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     constexpr int WR = (SZ == 2 && C >= 256) ? UF_QKV_RING : ((SZ == 2 && C >= 128) ? 3 : 2);
     const T* Wqkv = reinterpret_cast<const T*>(p.Wqkv);
     const T* wrow[6];
-    Frag<T> wf[WR][6];
+    Frag<T> wf[WR][LR ? 2 : 6];
     auto wload = [&](int ks, int slot) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+    };
+    // LR: step g of the flattened walk = (projection g / KS in the order k, v, q; k-step g % KS): two fragments
+    auto wload2 = [&](int g, int slot) {
+        const int pj = g / KS, ks = g - pj * KS, base = pj == 0 ? 2 : (pj == 1 ? 4 : 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) load_frag(wf[slot][i], wrow[base + i] + ks * 512);
     };
     auto unit_weights = [&](int u) {   // 16-row weight tiles of the unit's head in the fragment-major Wqkv (q tiles h*2+i, k tiles C/16+.., v tiles 2C/16+..) + ring prologue
         const int h = u / (4 / QT);
 #pragma unroll
         for (int i = 0; i < 6; ++i) wrow[i] = Wqkv + ((size_t)((i >> 1) * (C / 16) + h * 2 + (i & 1)) * KS * 64 + lane) * 8;
 #pragma unroll
-        for (int pf = 0; pf < WR - 1; ++pf)
-            if (pf < KS) wload(pf, pf);
+        for (int pf = 0; pf < WR - 1; ++pf) {
+            if constexpr (LR) { if (pf < 3 * KS) wload2(pf, pf); }
+            else { if (pf < KS) wload(pf, pf); }
+        }
     };
     if constexpr (HOIST) {
         if (wave < UNITS) unit_weights(wave);
@@ -371,6 +389,96 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
 #pragma unroll 1
     for (int u = wave; u < UNITS; u += WAVES) {
         const int h = u / (4 / QT), q0 = (u % (4 / QT)) * QT;   // head, first query tile
+        Frag<T> qf[QT], kf[4], vtf[2][2];
+        if constexpr (LR) {
+            // ---- low-register form: k, then v, then q; the ring runs across the three projections (3 KS steps) ----
+            if constexpr (!HOIST) unit_weights(u);
+            Frag<T> af[2][4];
+            auto aload2 = [&](int g, int slot) {      // activation fragments of step g: all four row tiles (k, v) or the unit's query tiles (q)
+                const int pj = g / KS, ks = g - pj * KS;
+                if (pj < 2 || QT == 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+                }
+            };
+            aload2(0, 0);
+            const f32x4 bk0 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + 16 + fg * 4);
+            {
+                f32x4 ak[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ak[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int g = ks;
+                    if (g + WR - 1 < 3 * KS) wload2(g + WR - 1, (g + WR - 1) % WR);
+                    aload2(g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16(ak[i][j], wf[g % WR][i], af[g & 1][j]);        // k: weight as A operand
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) FragFromAcc<T>::make(kf[j], ak[0][j] + bk0, ak[1][j] + bk1);
+            }
+            {
+                f32x4 av[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) av[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int g = KS + ks;
+                    if (g + WR - 1 < 3 * KS) wload2(g + WR - 1, (g + WR - 1) % WR);
+                    aload2(g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) mma16(av[i][j], af[g & 1][j], wf[g % WR][i]);        // v: activation as A operand
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float bv0 = Bq[2 * C + h * 32 + fr], bv1 = Bq[2 * C + h * 32 + 16 + fr];
+#pragma unroll
+                for (int sk = 0; sk < 2; ++sk) {
+                    FragFromAcc<T>::make(vtf[0][sk], av[0][2 * sk] + bv0, av[0][2 * sk + 1] + bv0);
+                    FragFromAcc<T>::make(vtf[1][sk], av[1][2 * sk] + bv1, av[1][2 * sk + 1] + bv1);
+                }
+            }
+            {
+                f32x4 aq[2][QT];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) aq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int g = 2 * KS + ks;
+                    if (g + WR - 1 < 3 * KS) wload2(g + WR - 1, (g + WR - 1) % WR);
+                    if (ks + 1 < KS) aload2(g + 1, (g + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < QT; ++j) mma16(aq[i][j], wf[g % WR][i], af[g & 1][j]);       // q: weight as A operand
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (u == wave) stamp(3);
+                if constexpr (HOIST) {
+                    if (u + WAVES < UNITS) unit_weights(u + WAVES);
+                }
+                const f32x4 bq0 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + fg * 4), bq1 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + 16 + fg * 4);
+#pragma unroll
+                for (int j = 0; j < QT; ++j) FragFromAcc<T>::make(qf[j], (aq[0][j] + bq0) * p.qscale, (aq[1][j] + bq1) * p.qscale);
+            }
+        } else {
         f32x4 aq[2][QT], ak[2][4], av[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -421,7 +529,6 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
             if (u + WAVES < UNITS) unit_weights(u + WAVES);
         }
         // bias (+ scale on q, model.py:497), then the accumulators ARE the attention operands
-        Frag<T> qf[QT], kf[4], vtf[2][2];
         {
             const f32x4 bq0 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + fg * 4), bq1 = *reinterpret_cast<const f32x4*>(Bq + h * 32 + 16 + fg * 4);
             const f32x4 bk0 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + fg * 4), bk1 = *reinterpret_cast<const f32x4*>(Bq + C + h * 32 + 16 + fg * 4);
@@ -435,6 +542,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
                 FragFromAcc<T>::make(vtf[0][sk], av[0][2 * sk] + bv0, av[0][2 * sk + 1] + bv0);
                 FragFromAcc<T>::make(vtf[1][sk], av[1][2 * sk] + bv1, av[1][2 * sk + 1] + bv1);
             }
+        }
         }
         // S^T = K Q^T : s[kt][j] -> lane: query (q0+j)*16+fr, keys 16kt+4fg+r
         f32x4 s[4][QT];
@@ -536,7 +644,7 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
         if (u == wave) stamp(4);
     }
     stamp(5);
-    std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
+    std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES, LR ? 2 : 4>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
     // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------
     {
         constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;
@@ -675,11 +783,11 @@ __global__ __launch_bounds__(NT, (sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) =
     census.end(p.tbuf, bw);
 }
 
-template <typename T, int C, int NT>
+template <typename T, int C, int NT, int LR = 0>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
     constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = attn_block_kernel<T, C, NT>;
+    auto kern = attn_block_kernel<T, C, NT, LR>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "attn_block")) return rc;
     char name[96] = "";
@@ -724,12 +832,16 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = debug_get_tbuf();
 
+    // low-register form at C <= 128 (see attn_block_kernel): UF_ATTN_LR=1 with the tighter register bound (one more workgroup per CU),
+    // =2 the same code at the occupancy of the first form, =0 the first form (A/B runs)
+    static const char* elr = getenv("UF_ATTN_LR");
+    const int lr = elr ? atoi(elr) : UF_ATTN_LR_DEFAULT;
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
 #define UF_AB_HALF(TT)                                                                                                              \
         switch (C) {                                                                                                                    \
-            case 32: UF_AB(TT, 32, 256);                                                                                                \
-            case 64: UF_AB(TT, 64, 256);                                                                                                \
-            case 128: UF_AB(TT, 128, 256);                                                                                              \
+            case 32: if (lr == 1) return launch_one<TT, 32, 256, 1>(p, st); if (lr == 2) return launch_one<TT, 32, 256, 2>(p, st); UF_AB(TT, 32, 256);      \
+            case 64: if (lr == 1) return launch_one<TT, 64, 256, 1>(p, st); if (lr == 2) return launch_one<TT, 64, 256, 2>(p, st); UF_AB(TT, 64, 256);      \
+            case 128: if (lr == 1) return launch_one<TT, 128, 256, 1>(p, st); if (lr == 2) return launch_one<TT, 128, 256, 2>(p, st); UF_AB(TT, 128, 256);                                                                                              \
             case 256:                                                                                                                   \
                 if (p.n_windows <= 256) UF_AB(TT, 256, 512);   /* one workgroup per CU at most: 8 waves (one head each) instead of 4 */ \
                 UF_AB(TT, 256, 256);                                                                                                    \
