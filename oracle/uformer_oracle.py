@@ -338,8 +338,10 @@ def ssim(img1: Tensor, img2: Tensor) -> float:
     utils/caculate_psnr_ssim.py:35-81 (crop_border 0, test_y_channel False)."""
     import numpy as np
     from scipy.signal import correlate2d
-    a = np.uint8((img1.clamp(0, 1).numpy() * 255.0).round()).astype(np.float64)
-    b = np.uint8((img2.clamp(0, 1).numpy() * 255.0).round()).astype(np.float64)
+    # (img * 255.0).round().astype(np.uint8) exactly as the reference writes it (:59-62): no clamp -- out-of-range values wrap modulo 256, as the
+    # float -> uint8 conversion does (spelled through int64 so that the wrap does not depend on the platform's float -> uint8 behaviour)
+    a = ((img1.numpy() * 255.0).round().astype(np.int64) & 255).astype(np.float64)        # float32 product and round, as the reference's
+    b = ((img2.numpy() * 255.0).round().astype(np.int64) & 255).astype(np.float64)
     k = np.exp(-((np.arange(11) - 5.0) ** 2) / (2 * 1.5 ** 2))
     k /= k.sum()                                     # cv2.getGaussianKernel(11, 1.5)
     window = np.outer(k, k)

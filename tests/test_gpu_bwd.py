@@ -18,9 +18,15 @@ TAG = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 F16_LOSS_SCALE = 65536.0       # torch.cuda.amp.GradScaler's initial scale (the reference trains under it, train/train_denoise.py:42,180-184)
 
 
-def pick(dtype, f32, bf16):
-    """tolerance by operand type: f16 = a quarter of bf16's (8x finer rounding, 2x headroom), never under f32's"""
-    return f32 if dtype == torch.float32 else (bf16 if dtype == torch.bfloat16 else max(f32, bf16 / 4))
+# Whole-model gates of the 2-byte modes = about twice what the kernels measure (VERDICT r03 "next" 8; measured on MI355X, profiles/r03_parity_grad_*.json:
+# gradients bf16 4.2e-2 / f16 5.1e-3 relative, restored images bf16 <= 2.1e-3): a 2x regression fails.
+GRAD_RTOL_BF16, GRAD_RTOL_F16 = 6e-2, 1e-2
+BF16_Y_TOL = 4e-3
+
+
+def pick(dtype, f32, bf16, f16=None):
+    """tolerance by operand type: f16 = a quarter of bf16's (8x finer rounding, 2x headroom) unless given, never under f32's"""
+    return f32 if dtype == torch.float32 else (bf16 if dtype == torch.bfloat16 else (f16 if f16 is not None else max(f32, bf16 / 4)))
 
 
 def rel(a, b):
@@ -102,6 +108,41 @@ def test_dwconv3x3_fused_backward(dtype, B, H, W, C):
     assert rel(dw9, rdw.reshape(C, 9).t()) < pick(dtype, 2e-4, 2e-3) and rel(db, rdb) < pick(dtype, 2e-4, 2e-3)
     da2, dw9b, dbb = ops.dwconv3x3_bwd(dc, flip, pre)
     assert torch.equal(da, da2) and torch.equal(dw9, dw9b) and torch.equal(db, dbb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dwconv3x3_fused_backward_chunked(dtype):
+    """Tensors of 4 GiB or more (32-bit byte offsets in the kernels) are walked in chunks of whole images with the tap / bias gradients added in chunk
+    order (the one-pass form used to return UF_ERR_SHAPE where the two-kernel form worked).  The limit is lowered through
+    UF_DWBWD_MAX_BYTES in a fresh process so that a small tensor takes the chunked path: input gradient bit-identical to the unchunked run, tap /
+    bias gradients equal up to the summation order."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, torch
+sys.path.insert(0, %r)
+from uformer_amd import ops
+dt = {"f32": torch.float32, "bf16": torch.bfloat16}[sys.argv[1]]
+g = torch.Generator().manual_seed(5)
+pre = torch.randn(7, 16, 24, 64, generator=g).to(dt).cuda(); dc = torch.randn(7, 16, 24, 64, generator=g).to(dt).cuda()
+flip = (torch.randn(9, 64, generator=g) * 0.3).cuda()
+da, dw, db = ops.dwconv3x3_bwd(dc, flip, pre)
+torch.save((da.cpu(), dw.cpu(), db.cpu()), sys.argv[2])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tag = "f32" if dtype == torch.float32 else "bf16"
+    outs = []
+    for lim in ("0", str(2 * 16 * 24 * 64 * (4 if dtype == torch.float32 else 2) + 1)):     # 0 = the real 4 GiB limit; then two images per chunk
+        path = f"/tmp/dwbwd_{tag}_{lim}.pt"
+        env = dict(os.environ)
+        if lim != "0":
+            env["UF_DWBWD_MAX_BYTES"] = lim
+        subprocess.check_call([sys.executable, "-c", code, tag, path], env=env)
+        outs.append(torch.load(path))
+    (da0, dw0, db0), (da1, dw1, db1) = outs
+    assert torch.equal(da0, da1)
+    assert rel(dw1, dw0) < 2e-5 and rel(db1, db0) < 2e-5
+    assert not torch.equal(dw0, torch.zeros_like(dw0))
 
 
 @pytest.mark.parametrize("dtype", MODES)
@@ -329,7 +370,7 @@ def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
     the C-ABI kernels against the REFERENCE's autograd (tests/golden/grad_model_B_256.npz): loss, restored image, d loss /
     d input, and EVERY one of the 719 parameter gradients through two signed random projections and a seeded gather or the
     full tensor (tests/fixture_checks.py) -- a permuted or transposed gradient cannot pass.
-    Tolerances: f32 2e-3 (of ||g|| / max|g|), bf16 1e-1, the ones of the tiny32 test above; f16 2.5e-2 (bf16's / 4: derived from the
+    Tolerances: f32 2e-3 (of ||g|| / max|g|), bf16 6e-2 and f16 1e-2 (twice the measured errors, GRAD_RTOL_*); (round 3: f16 was bf16's / 4, derived from the
     mantissa widths) with the loss scaled by 65536 as under the reference's GradScaler -- d loss / d y is 5e-6 here, below f16's
     smallest normal number."""
     import fixture_checks as FC
@@ -347,7 +388,7 @@ def test_uformer_B_256_backward_vs_reference_autograd(golden, dtype):
     y, dimg, grads = train.uformer_forward_backward(x.cuda(), sd, dy.cuda(), cfg=cfg, dtype=dtype,
                                                     loss_scale=F16_LOSS_SCALE if dtype == torch.float16 else 1.0)
     # f16: the restored image meets the 1e-3 north-star tolerance like f32; gradients a quarter of the bf16 tolerance
-    worst = FC.check_grad_B(gd, loss_ref, y, dimg, grads, rtol=pick(dtype, 2e-3, 1e-1), loss_tol=1e-6, y_tol=8e-3 if dtype == torch.bfloat16 else 1e-3)
+    worst = FC.check_grad_B(gd, loss_ref, y, dimg, grads, rtol=pick(dtype, 2e-3, GRAD_RTOL_BF16, GRAD_RTOL_F16), loss_tol=1e-6, y_tol=BF16_Y_TOL if dtype == torch.bfloat16 else 1e-3)
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)
@@ -579,7 +620,7 @@ def test_uformer_T_head_dim16_trains_vs_reference_autograd(golden, dtype):
     nn.Module boundary with the DropPath masks the reference drew, loss.backward(), against the REFERENCE's autograd
     (tests/golden/grad_model_T_128.npz: loss, restored images, d loss / d input, every parameter through signed probes).
     head_dim-16 blocks take the op-by-op forward + op-level backward with window_attn_bwd<16> (VERDICT r02 "missing" 2).
-    Tolerances as the Uformer-B test: f32 2e-3, bf16 1e-1, f16 2.5e-2 (scaled loss)."""
+    Tolerances as the Uformer-B test: f32 2e-3, bf16 6e-2, f16 1e-2 (scaled loss)."""
     import fixture_checks as FC
     import numpy as np
     from uformer_amd import model, spec
@@ -604,8 +645,10 @@ def test_uformer_T_head_dim16_trains_vs_reference_autograd(golden, dtype):
     else:
         loss.backward()
     grads = {n: (None if p_.grad is None else p_.grad / ls) for n, p_ in m.named_parameters()}
-    worst = FC.check_grad_T(gd, float(gd["loss"]) if dtype != torch.float32 else loss.item(), y.detach(), x.grad / ls, grads, rtol=pick(dtype, 2e-3, 1e-1), loss_tol=1e-5,
-                            y_tol=8e-3 if dtype == torch.bfloat16 else 1e-3)
+    # the loss of THIS forward in every operand type (the 2-byte modes used to pass the golden value to its own check); its tolerance
+    # follows the output tolerance: |d loss| <= mean |d y| for the Charbonnier loss
+    worst = FC.check_grad_T(gd, loss.item(), y.detach(), x.grad / ls, grads, rtol=pick(dtype, 2e-3, GRAD_RTOL_BF16, GRAD_RTOL_F16), loss_tol=pick(dtype, 1e-5, 2e-3),
+                            y_tol=BF16_Y_TOL if dtype == torch.bfloat16 else 1e-3)
     import json
     import os
     os.makedirs("gpurun_out", exist_ok=True)

@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_walk_kernel(const T* __r
 // dw9[t][c] (t < 9) and dbias[c] (t == 9) = sum over the workgroups w = cblk, cblk + cb, ... of partial[w][t][c within the block].
 // 32 outputs per workgroup, 8 p-lanes per output (every 8th workgroup, in order), lane sums added in lane order: fixed order.
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_finalize(const float* __restrict__ partial, int blocks, int cb, int cgN, float* __restrict__ dw9,
-                                                             float* __restrict__ dbias, int C) {
+                                                             float* __restrict__ dbias, int C, int accumulate) {
     __shared__ float sh[8][33];
     const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int j = blockIdx.x * 32 + col;   // over 10 * C outputs
@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_finalize(const float* __res
         float r = sh[0][col];
 #pragma unroll
         for (int k = 1; k < 8; ++k) r += sh[k][col];
-        if (t < 9) dw9[(size_t)t * C + c] = r; else dbias[c] = r;
+        float* dst = t < 9 ? dw9 + (size_t)t * C + c : dbias + c;
+        *dst = accumulate ? *dst + r : r;           // accumulate: a later image chunk of a tensor of 4 GiB or more (fixed chunk order)
     }
 }
 
@@ -1378,7 +1379,14 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
     const int Nn = dtype_half(dtype) ? 8 : 4;
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % Nn == 0 && H % DWB_R == 0, UF_ERR_SHAPE,
                "uf_dwconv3x3_bwd: B=%d H=%d W=%d C=%d (C multiple of %d, H multiple of %d)", B, H, W, C, Nn, DWB_R);
-    UF_REQUIRE((unsigned long long)B * H * W * C * dtype_size(dtype) < 0xffffffffULL, UF_ERR_SHAPE, "uf_dwconv3x3_bwd: tensor of 4 GiB or more: split the batch");
+    // The kernels address the tensor with 32-bit byte offsets.  A tensor of 4 GiB or more (f32 256 x 256 at batch 64 in the last decoder stage, 512 x 512
+    // at f32 batch 16 / bf16 batch 32 -- shapes the two-kernel form handled) is walked in chunks of whole images, each under the limit; the tap / bias
+    // gradients of the chunks are added in chunk order by the finalize kernel (the one-pass form used to fail with UF_ERR_SHAPE there).
+    // UF_DWBWD_MAX_BYTES lowers the limit (tests).
+    static const unsigned long long lim_env = getenv("UF_DWBWD_MAX_BYTES") ? strtoull(getenv("UF_DWBWD_MAX_BYTES"), nullptr, 10) : 0ULL;
+    const unsigned long long limit = lim_env ? lim_env : 0xffffffffULL, per_img = (unsigned long long)H * W * C * dtype_size(dtype);
+    UF_REQUIRE(per_img < limit, UF_ERR_SHAPE, "uf_dwconv3x3_bwd: one image of the tensor has %llu bytes (32-bit offsets: under %llu)", per_img, limit);
+    const int chunkB = (int)((limit - 1) / per_img) < B ? (int)((limit - 1) / per_img) : B;
     UF_REQUIRE(((uintptr_t)dc % 16) == 0 && ((uintptr_t)pre % 16) == 0 && ((uintptr_t)da % 16) == 0 && ((uintptr_t)w9_flipped % 16) == 0, UF_ERR_ALIGN,
                "uf_dwconv3x3_bwd: operands must be 16-byte aligned");
     const size_t need = uf_dwconv3x3_bwd_workspace_bytes(C, dtype);
@@ -1390,24 +1398,31 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
     static const bool walk = !(getenv("UF_DWCONV_WALK") && atoi(getenv("UF_DWCONV_WALK")) == 0);   // 0: one pixel column per thread (A/B)
     // the walking form for the 2-byte types (with f32 operands its 72 column registers on top of the erf-form GELU spill)
     const int seg = (walk && dtype_half(dtype) && W % 8 == 0) ? (W % 16 == 0 ? 16 : 8) : 0;
-#define UF_DWBWD_ARGS dim3(blocks), dim3(256), 0, st, (const TT*)dc, w9_flipped, (const TT*)pre, (TT*)da, (float*)ws, B, H, W, C, lg
-    if (dtype == UF_F32) { using TT = float; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
-    else if (dtype == UF_BF16) {
-        using TT = bf16;
-        if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
-        else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
-        else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
-    } else {
-        using TT = f16;
-        if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
-        else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
-        else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
-    }
+    for (int b0 = 0; b0 < B; b0 += chunkB) {
+        const int Bc = B - b0 < chunkB ? B - b0 : chunkB;
+        const size_t off = (size_t)b0 * per_img;
+        const char* dcc = (const char*)dc + off; const char* prec = (const char*)pre + off; char* dac = (char*)da + off;
+#define UF_DWBWD_ARGS dim3(blocks), dim3(256), 0, st, (const TT*)dcc, w9_flipped, (const TT*)prec, (TT*)dac, (float*)ws, Bc, H, W, C, lg
+        if (dtype == UF_F32) { using TT = float; hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS); }
+        else if (dtype == UF_BF16) {
+            using TT = bf16;
+            if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
+            else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
+            else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
+        } else {
+            using TT = f16;
+            if (seg == 16) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 16>), UF_DWBWD_ARGS);
+            else if (seg == 8) hipLaunchKernelGGL((dwconv3x3_bwd_walk_kernel<TT, 8>), UF_DWBWD_ARGS);
+            else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<TT, 4, DWB_R>), UF_DWBWD_ARGS);
+        }
 #undef UF_DWBWD_ARGS
-    int rc = check_launch("dwconv3x3_bwd");
-    if (rc) return rc;
-    hipLaunchKernelGGL(dwconv3x3_bwd_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks, cb, 4 << lg, dw9, dbias, C);
-    return check_launch("dwconv3x3_bwd_finalize");
+        int rc = check_launch("dwconv3x3_bwd");
+        if (rc) return rc;
+        hipLaunchKernelGGL(dwconv3x3_bwd_finalize, dim3((10 * C + 31) / 32), dim3(256), 0, st, (const float*)ws, blocks, cb, 4 << lg, dw9, dbias, C, b0 > 0 ? 1 : 0);
+        rc = check_launch("dwconv3x3_bwd_finalize");
+        if (rc) return rc;
+    }
+    return UF_OK;
 }
 
 static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullptr; return !off; }   // UF_WGRAD_V1=1: first version (A/B, tests)

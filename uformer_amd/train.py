@@ -340,6 +340,31 @@ def _conv3x3_backward(x: Tensor, nchw: bool, geom: Tuple[int, int, int, int], w:
     return _conv_backward(x, nchw, geom, w, dy_rows, 1, 1, T)
 
 
+_RECOMPUTE_CHOICE: Dict[tuple, bool] = {}
+
+
+def choose_recompute(cfg, B: int, H: int, device) -> bool:
+    """Kept-intermediates or recompute form for (arch, batch, resolution) on this device -- decided ONCE and remembered, so every step of a run (and,
+    under DDP, every rank: the choice is reduced with MAX over the process group) takes the same kernels and rounds the same way (the
+    per-forward decision compared against the driver's free memory, which excludes what PyTorch's caching allocator reserved on the previous step,
+    and could flip between steps or differ between ranks).  The memory that counts as available = the driver's free bytes + the allocator's
+    reserved-but-unallocated bytes."""
+    key = (tuple(cfg.depths), cfg.embed_dim, B, H, torch.device(device).index)
+    if key not in _RECOMPUTE_CHOICE:
+        dims, div = cfg.stage_dims(), cfg.stage_res_div()
+        need = 60 * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
+        free = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        choice = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 356 vs 357 img/s): keep the small one
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            flag = torch.tensor([1.0 if choice else 0.0], device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            choice = bool(flag.item() > 0)
+        _RECOMPUTE_CHOICE[key] = choice
+        if os.environ.get("UF_TRAIN_VERBOSE"):
+            print(f"[uformer_amd.train] batch {B} at {H}x{H}: {'recompute' if choice else 'kept-intermediates'} form ({need / 1e9:.1f} GB of intermediates, {free / 1e9:.1f} GB available)", flush=True)
+    return _RECOMPUTE_CHOICE[key]
+
+
 class UformerTape:
     """One forward of the whole model (model.py:1269-1305) that keeps what the reverse sweep reads, and that sweep.
     ``drop_scales``: None (eval semantics) or a (2 * n_blocks, B) tensor of DropPath scales in execution order.
@@ -364,10 +389,18 @@ class UformerTape:
             # Keeping every intermediate of the op-by-op forward costs ~60 bytes per token x channel of every block (measured: 56 GB for
             # Uformer-B 256^2 at batch 32 against 17 GB) and saves the recomputation in the backward: 371 vs 334 img/s on an MI355X
             # (profiles/r03_host.txt).  288 GB of HBM is there to be used: keep them while that is under half of the free memory.
-            dims, div = cfg.stage_dims(), cfg.stage_res_div()
-            need = 60 * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
-            free = torch.cuda.mem_get_info(img.device)[0]
-            self.recompute = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 356 vs 357 img/s): keep the small one
+            self.recompute = choose_recompute(cfg, B, H, img.device)
+        # widths the training kernels cover, checked once with a clear message (they used to fail deep inside the tape with UF_ERR_SHAPE)
+        dims_ = cfg.stage_dims()
+        for s_ in range(9):
+            hd_ = dims_[s_] // max(1, cfg.num_heads[s_])
+            if dims_[s_] % cfg.num_heads[s_] or hd_ not in (16, 32) or dims_[s_] % 16:
+                raise ops.UformerHipError(f"training: stage {s_} has {dims_[s_]} channels over {cfg.num_heads[s_]} heads (head_dim {hd_}); supported: head_dim 16 or 32, "
+                                          f"channels a multiple of 16 (every get_arch architecture, utils/model_utils.py:56-81)")
+        if self.recompute and not any(dims_[s_] == 32 * cfg.num_heads[s_] for s_ in range(9)):
+            import warnings
+            warnings.warn("recompute=True was requested, but no stage has head_dim 32 (the fused kernels the recompute form is built on): every block keeps its "
+                          "intermediates (memory ~18x the recompute form)", stacklevel=2)
         shifts = cfg.block_shifts()
         res = self.res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
         first = [sum(cfg.depths[:s]) for s in range(9)]
