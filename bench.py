@@ -178,6 +178,10 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
     B = args.train_batch
     x = spec.synth_input(B, args.img, args.img, 1234 + 2 * rank).to(dev)
     tgt = spec.synth_input(B, args.img, args.img, 1235 + 2 * rank).to(dev)
+    # f16 operands train under the reference's protocol (torch.cuda.amp.GradScaler through timm's NativeScaler, train/train_denoise.py:42, :180-184):
+    # a DYNAMIC loss scale starting at 65536 with an inf / nan check and a skipped step on overflow -- uformer_amd.optim.GradScaler keeps all of it on
+    # the device (no host synchronisation in the step); bf16 / f32 need no scale
+    scaler = uo.GradScaler(device=dev) if dtype_name == "f16" else None
     ls = 65536.0 if dtype_name == "f16" else 1.0
     world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     sink = ud.OverlappedGradientAllReduce(m) if world > 1 else None
@@ -190,10 +194,15 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
         else:
             opt.zero_grad(set_to_none=True)
         loss = crit(m(x), tgt)
-        (loss * ls if ls != 1.0 else loss).backward()
+        (scaler.scale(loss) if scaler is not None else loss).backward()
         if sink is not None:
             sink.finish()
-        opt.step(grad_scale=(sink.grad_scale if sink is not None else 1.0) / ls)
+        gsc = sink.grad_scale if sink is not None else 1.0
+        if scaler is not None:
+            scaler.step(opt, grad_scale=gsc)
+            scaler.update()
+        else:
+            opt.step(grad_scale=gsc)
         state["loss"] = loss
 
     for _ in range(max(1, args.train_warmup)):
@@ -207,7 +216,9 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
     flops_img = 3 * 2.0 * m.flops()                        # FLOPs_train = 3 x forward
     v = world * B / dt
     out = {"workload": f"{args.arch} {args.img}x{args.img} training step (fwd + bwd + Charbonnier + AdamW), batch {B}/GPU, DropPath 0.1, synthetic data",
-           "images_per_s": v, "ms_per_step": 1e3 * dt, "steps": args.train_steps, "batch_per_gpu": B, "dtype": dtype_name, "loss_scale": ls,
+           "images_per_s": v, "ms_per_step": 1e3 * dt, "steps": args.train_steps, "batch_per_gpu": B, "dtype": dtype_name,
+           "loss_scale": (scaler.get_scale() if scaler is not None else 1.0), "loss_scale_policy": ("dynamic (device-side GradScaler)" if scaler is not None else "none"),
+           "loss_is_finite": bool(torch.isfinite(state["loss"]).item()),
            "loss": float(state["loss"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
            "mfma_frac_whole_step": v * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[dtype_name],
            "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}

@@ -426,6 +426,21 @@ int uf_adamw_step(float* const* params, const float* const* grads, float* const*
                   const long long* numel, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
                   int step, double grad_scale, void* stream);
 
+/* f16 training under a DYNAMIC loss scale, entirely on the device: torch.cuda.amp.GradScaler semantics as the reference uses them through timm's
+ * NativeScaler (train/train_denoise.py:42, :180-184: scale the loss, unscale + inf check, skip the optimizer step on overflow, grow / back off).
+ * scaler_state: device float[8] = {scale, 1 / scale, found_inf, growth tracker, optimizer steps taken, 0, 0, 0}; the caller initialises
+ * {S, 1 / S, 0, 0, 0} (GradScaler: S = 65536) and multiplies the loss by S (reading state[0] on the device, or knowing S on the host).
+ *   uf_grad_scaler_check   state[2] = 1 if any element of the gradients is inf / nan (never cleared here)
+ *   uf_adamw_step_scaled   uf_adamw_step with gradients x grad_scale x state[1], NOTHING written when state[2] != 0, and the bias corrections taken
+ *                          at step state[4] + 1 -- a skipped step does not advance the optimizer, as GradScaler.step never calls optimizer.step then
+ *   uf_grad_scaler_update  GradScaler.update(): overflow -> scale *= backoff_factor, tracker = 0; else state[4] += 1 and after growth_interval clean
+ *                          steps in a row scale *= growth_factor; refreshes 1 / scale and clears found_inf.  No host synchronisation anywhere. */
+int uf_grad_scaler_check(const float* const* grads, const long long* numel, int n_tensors, float* scaler_state, void* stream);
+int uf_adamw_step_scaled(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                         const long long* numel, int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay,
+                         double grad_scale, const float* scaler_state, void* stream);
+int uf_grad_scaler_update(float* scaler_state, double growth_factor, double backoff_factor, int growth_interval, void* stream);
+
 /* ---- f-3: evaluation metrics on the device ------------------------------------------------------------------------
  * per-image mean squared difference of (optionally [0,1]-clamped) images: myPSNR = 20 log10(1 / sqrt(mse)) and batch_PSNR
  * (utils/image_utils.py:40-51) follow from it without copying an image to the host.  a, b: f32 (n_images, C, H, W). */

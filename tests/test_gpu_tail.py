@@ -109,6 +109,51 @@ def test_checkpoint_roundtrip_in_reference_format(tmp_path):
         assert torch.allclose(a, b, rtol=1e-6, atol=1e-9)
 
 
+def test_dynamic_loss_scaler_matches_torch_gradscaler_semantics():
+    """uformer_amd.optim.GradScaler + AdamW (all decisions on the device: uf_grad_scaler_check / uf_adamw_step_scaled / uf_grad_scaler_update) against
+    the protocol of torch.cuda.amp.GradScaler the reference trains under (train/train_denoise.py:180-184), restated on the CPU: unscale, skip the
+    optimizer step and halve the scale when a gradient is inf / nan, double the scale after ``growth_interval`` clean steps, and -- because a skipped
+    step never reaches the optimizer -- Adam's bias corrections count only the steps actually taken."""
+    from uformer_amd import optim as uo
+    torch.manual_seed(11)
+    shapes = [(33, 7), (5,), (4, 3, 3, 3), (70000,)]
+    params = [torch.randn(*sh) for sh in shapes]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in params]
+    got_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    ref_opt = torch.optim.AdamW(ref_p, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    opt = uo.AdamW(got_p, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    scaler = uo.GradScaler(init_scale=1024.0, growth_interval=3)
+    ref_scale, tracker, taken = 1024.0, 0, 0
+    overflow_at = {2: float("inf"), 5: float("nan")}                     # steps whose gradients overflow
+    for step in range(9):
+        grads = [torch.randn(*sh, generator=torch.Generator().manual_seed(100 * step + i)) for i, sh in enumerate(shapes)]
+        scaled = [g * ref_scale for g in grads]                           # what backward() of the scaled loss leaves in .grad
+        if step in overflow_at:
+            scaled[step % len(shapes)].view(-1)[3] = overflow_at[step]
+        for p_, g in zip(got_p, scaled):
+            p_.grad = g.clone().cuda()
+        assert abs(scaler.get_scale() - ref_scale) == 0.0
+        scaler.step(opt)
+        scaler.update()
+        # reference protocol on the CPU
+        if any(not torch.isfinite(g).all() for g in scaled):
+            ref_scale *= 0.5; tracker = 0
+        else:
+            for p_, g in zip(ref_p, scaled):
+                p_.grad = g / ref_scale
+            ref_opt.step(); taken += 1; tracker += 1
+            if tracker == 3:
+                ref_scale *= 2.0; tracker = 0
+        for a, b in zip(got_p, ref_p):
+            assert torch.allclose(a.detach().cpu(), b.detach(), rtol=2e-6, atol=1e-8), (step, (a.detach().cpu() - b.detach()).abs().max().item())
+    assert scaler.steps_taken() == taken == 7 and abs(scaler.get_scale() - ref_scale) == 0.0
+    scaler.sync_steps(opt)
+    assert all(int(st["step"]) == 7 for st in opt.state.values())
+    sd = scaler.state_dict()
+    s2 = uo.GradScaler(); s2.load_state_dict(sd)
+    assert s2.get_scale() == scaler.get_scale() and s2.steps_taken() == 7
+
+
 def test_batch_psnr_and_ssim_vs_reference_formulas():
     from uformer_amd import metrics
     a = torch.rand(3, 3, 72, 200, generator=g(1)) * 1.3 - 0.15             # values outside [0,1]: the clamp matters

@@ -132,6 +132,9 @@ SIGNATURES = {
     "uf_charbonnier_workspace_bytes": (c_size_t, [C.c_longlong]),
     "uf_charbonnier_fwd_bwd": (I, [P, P, P, P, C.c_longlong, C.c_float, C.c_float, P, c_size_t, P]),
     "uf_adamw_step": (I, [P, P, P, P, P, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I, C.c_double, P]),
+    "uf_grad_scaler_check": (I, [P, P, I, P, P]),
+    "uf_adamw_step_scaled": (I, [P, P, P, P, P, I, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, P, P]),
+    "uf_grad_scaler_update": (I, [P, C.c_double, C.c_double, I, P]),
     "uf_image_metric_workspace_bytes": (c_size_t, [I, I, I, I]),
     "uf_batch_mse": (I, [P, P, P, I, I, I, I, I, P, c_size_t, P]),
     "uf_batch_ssim": (I, [P, P, P, I, I, I, I, P, c_size_t, P]),

@@ -76,6 +76,10 @@ struct AdamWArgs {
     int first_chunk[AW_MAX + 1];         // prefix sums of ceil(n / AW_CHUNK)
     int count;
     float decay, omb1, omb2, b2, step, bc2s, eps, gs;   // host doubles rounded once, as torch's Python scalars are: 1 - lr*wd, 1 - b1, 1 - b2, lr / (1 - b1^t), sqrt(1 - b2^t)
+    // dynamic loss scale on the device (uf_adamw_step_scaled): state = {scale, 1 / scale, found_inf, growth tracker, good steps}; NULL = plain step.
+    // With it the gradient factor is gs * state[1], the update is skipped when state[2] != 0, and the bias corrections use step state[4] + 1.
+    const float* scaler;
+    double lr, beta1, beta2;
 };
 // torch.optim.AdamW (decoupled weight decay), single-tensor formulas, f32 state:
 //   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2 v + (1-b2) g g;  p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)
@@ -88,12 +92,20 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamWArgs a) {
     const long long base = (long long)(c - a.first_chunk[t]) * AW_CHUNK;
     const long long n = a.n[t];
     float* __restrict__ p = a.p[t]; const float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
+    float gs = a.gs, stepf = a.step, bc2s = a.bc2s;
+    if (a.scaler) {                                     // GradScaler semantics (train/train_denoise.py:180-184): unscale, skip on inf / nan
+        if (a.scaler[2] != 0.0f) return;                // found_inf: the whole step is skipped (wave-uniform)
+        gs *= a.scaler[1];
+        const double t = (double)a.scaler[4] + 1.0;     // optimizer steps actually taken so far + 1
+        stepf = (float)(a.lr / (1.0 - pow(a.beta1, t)));
+        bc2s = (float)sqrt(1.0 - pow(a.beta2, t));
+    }
     auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-        gg *= a.gs;
+        gg *= gs;
         pp *= a.decay;
         mm = mm + a.omb1 * (gg - mm);
         vv = vv * a.b2 + a.omb2 * (gg * gg);
-        pp -= a.step * (mm / (sqrtf(vv) / a.bc2s + a.eps));
+        pp -= stepf * (mm / (sqrtf(vv) / bc2s + a.eps));
     };
     const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     if (vec) {
@@ -297,8 +309,38 @@ extern "C" int uf_charbonnier_fwd_bwd(const float* y, const float* target, float
     return check_launch("charbonnier");
 }
 
-extern "C" int uf_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
-                             int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+// found_inf (multi-tensor, 40 tensors per launch): state[2] = 1 if any gradient element is inf or nan (torch's _amp_foreach_non_finite_check_and_unscale_
+// without the unscale, which uf_adamw_step_scaled folds into its gradient factor)
+struct FoundInfArgs { const float* g[AW_MAX]; long long n[AW_MAX]; int first_chunk[AW_MAX + 1]; int count; float* state; };
+__global__ __launch_bounds__(256) void found_inf_kernel(const FoundInfArgs a) {
+    int t = 0;
+    const int c = blockIdx.x;
+#pragma unroll 1
+    while (t + 1 < a.count && c >= a.first_chunk[t + 1]) ++t;
+    const long long base = (long long)(c - a.first_chunk[t]) * AW_CHUNK, n = a.n[t];
+    const float* __restrict__ g = a.g[t];
+    bool bad = false;
+    for (int k = threadIdx.x; k < AW_CHUNK; k += 256) {
+        const long long i = base + k;
+        if (i < n) { const float v = g[i]; bad = bad || !(fabsf(v) <= 3.4028234e38f); }      // false for inf and for nan
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && threadIdx.x == 0) a.state[2] = 1.0f;                 // racing writers store the same value
+}
+// GradScaler.update(): found_inf -> scale *= backoff, tracker = 0; else ++good steps, ++tracker, scale *= growth every `interval` clean steps
+__global__ void scaler_update_kernel(float* state, float growth, float backoff, int interval) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float scale = state[0], tracker = state[3];
+    if (state[2] != 0.0f) { scale *= backoff; tracker = 0.0f; }
+    else {
+        state[4] += 1.0f;
+        tracker += 1.0f;
+        if (tracker >= (float)interval) { scale *= growth; tracker = 0.0f; }
+    }
+    state[0] = scale; state[1] = 1.0f / scale; state[2] = 0.0f; state[3] = tracker;
+}
+
+static int adamw_any(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
+                     int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, const float* scaler, void* stream) {
     UF_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel, UF_ERR_NULL, "uf_adamw_step: null pointer");
     UF_REQUIRE(n_tensors >= 0 && step >= 1, UF_ERR_SHAPE, "uf_adamw_step: n_tensors=%d step=%d (step counts from 1)", n_tensors, step);
     hipStream_t st = (hipStream_t)stream;
@@ -308,6 +350,7 @@ extern "C" int uf_adamw_step(float* const* params, const float* const* grads, fl
         AdamWArgs a{};
         a.decay = (float)(1.0 - lr * weight_decay); a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
         a.b2 = (float)beta2; a.step = (float)(lr / bc1); a.bc2s = (float)sqrt(bc2); a.eps = (float)eps; a.gs = (float)grad_scale;
+        a.scaler = scaler; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2;
         int c = 0, chunks = 0;
         double elems = 0;
         for (; i < n_tensors && c < AW_MAX; ++i) {
@@ -329,6 +372,52 @@ extern "C" int uf_adamw_step(float* const* params, const float* const* grads, fl
         if (int rc = check_launch("adamw")) return rc;
     }
     return UF_OK;
+}
+
+extern "C" int uf_adamw_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
+                             int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale, void* stream) {
+    return adamw_any(params, grads, exp_avg, exp_avg_sq, numel, n_tensors, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, stream);
+}
+
+extern "C" int uf_adamw_step_scaled(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq, const long long* numel,
+                                    int n_tensors, double lr, double beta1, double beta2, double eps, double weight_decay, double grad_scale,
+                                    const float* scaler_state, void* stream) {
+    UF_REQUIRE(scaler_state, UF_ERR_NULL, "uf_adamw_step_scaled: null scaler state");
+    return adamw_any(params, grads, exp_avg, exp_avg_sq, numel, n_tensors, lr, beta1, beta2, eps, weight_decay, 1, grad_scale, scaler_state, stream);
+}
+
+extern "C" int uf_grad_scaler_check(const float* const* grads, const long long* numel, int n_tensors, float* scaler_state, void* stream) {
+    UF_REQUIRE(grads && numel && scaler_state, UF_ERR_NULL, "uf_grad_scaler_check: null pointer");
+    UF_REQUIRE(n_tensors >= 0, UF_ERR_SHAPE, "uf_grad_scaler_check: n_tensors=%d", n_tensors);
+    hipStream_t st = (hipStream_t)stream;
+    int i = 0;
+    while (i < n_tensors) {
+        FoundInfArgs a{};
+        a.state = scaler_state;
+        int c = 0, chunks = 0;
+        for (; i < n_tensors && c < AW_MAX; ++i) {
+            if (numel[i] <= 0) continue;
+            UF_REQUIRE(grads[i], UF_ERR_NULL, "uf_grad_scaler_check: tensor %d is null", i);
+            const long long nch = (numel[i] + AW_CHUNK - 1) / AW_CHUNK;
+            UF_REQUIRE(chunks + nch < 0x7fffffffLL, UF_ERR_SHAPE, "uf_grad_scaler_check: too many elements in one launch");
+            a.g[c] = grads[i]; a.n[c] = numel[i]; a.first_chunk[c] = chunks;
+            chunks += (int)nch;
+            ++c;
+        }
+        if (c == 0) break;
+        a.first_chunk[c] = chunks; a.count = c;
+        hipLaunchKernelGGL(found_inf_kernel, dim3(chunks), dim3(256), 0, st, a);
+        if (int rc = check_launch("grad_scaler_check")) return rc;
+    }
+    return UF_OK;
+}
+
+extern "C" int uf_grad_scaler_update(float* scaler_state, double growth_factor, double backoff_factor, int growth_interval, void* stream) {
+    UF_REQUIRE(scaler_state, UF_ERR_NULL, "uf_grad_scaler_update: null pointer");
+    UF_REQUIRE(growth_factor > 1.0 && backoff_factor > 0.0 && backoff_factor < 1.0 && growth_interval >= 1, UF_ERR_SHAPE,
+               "uf_grad_scaler_update: growth %g (> 1), backoff %g (in (0, 1)), interval %d (>= 1)", growth_factor, backoff_factor, growth_interval);
+    hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scaler_state, (float)growth_factor, (float)backoff_factor, growth_interval);
+    return check_launch("grad_scaler_update");
 }
 
 extern "C" size_t uf_image_metric_workspace_bytes(int n_images, int C, int H, int W) {

@@ -592,6 +592,52 @@ def adamw_step(params, grads, exp_avg, exp_avg_sq, *, lr: float, betas=(0.9, 0.9
                                              weight_decay, int(step), grad_scale, _stream()), "uf_adamw_step")
 
 
+def adamw_step_scaled(params, grads, exp_avg, exp_avg_sq, scaler_state: Tensor, *, lr: float, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.02,
+                      grad_scale: float = 1.0) -> None:
+    """``adamw_step`` under a device-resident dynamic loss scale (uf_adamw_step_scaled): gradients x grad_scale / scale, nothing written when
+    ``scaler_state[2]`` (found_inf) is set, bias corrections at step ``scaler_state[4] + 1``.  No host synchronisation."""
+    import ctypes as C
+    n = len(params)
+    if not (len(grads) == len(exp_avg) == len(exp_avg_sq) == n):
+        raise UformerHipError("adamw_step_scaled: list lengths differ")
+    if n == 0:
+        return
+    dev = _dev(*params, *grads, *exp_avg, *exp_avg_sq, scaler_state)
+    for group in (params, grads, exp_avg, exp_avg_sq, [scaler_state]):
+        for t in group:
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise UformerHipError("adamw_step_scaled: tensors must be contiguous float32")
+    arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])      # noqa: E731
+    numel = (C.c_longlong * n)(*[p.numel() for p in params])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().uf_adamw_step_scaled(arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, n, lr, betas[0], betas[1], eps,
+                                                    weight_decay, grad_scale, _ptr(scaler_state), _stream()), "uf_adamw_step_scaled")
+
+
+def grad_scaler_check(grads, scaler_state: Tensor) -> None:
+    """scaler_state[2] = 1 if any gradient element is inf / nan (uf_grad_scaler_check)."""
+    import ctypes as C
+    grads = [g for g in grads if g is not None]
+    n = len(grads)
+    if n == 0:
+        return
+    dev = _dev(*grads, scaler_state)
+    for t in grads:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise UformerHipError("grad_scaler_check: gradients must be contiguous float32")
+    arr = (C.c_void_p * n)(*[t.data_ptr() for t in grads])
+    numel = (C.c_longlong * n)(*[t.numel() for t in grads])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().uf_grad_scaler_check(arr, numel, n, _ptr(scaler_state), _stream()), "uf_grad_scaler_check")
+
+
+def grad_scaler_update(scaler_state: Tensor, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000) -> None:
+    """GradScaler.update() on the device (uf_grad_scaler_update)."""
+    _dev(scaler_state)
+    with torch.cuda.device(scaler_state.device):
+        _lib.check(_lib.load().uf_grad_scaler_update(_ptr(scaler_state), growth_factor, backoff_factor, int(growth_interval), _stream()), "uf_grad_scaler_update")
+
+
 def batch_mse(a: Tensor, b: Tensor, clamp01: bool = True) -> Tensor:
     """Per-image mean squared difference of (B,C,H,W) f32 images, clamped to [0,1] first (myPSNR, utils/image_utils.py:40-44)."""
     _dev(a, b)
