@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""round 4 debugging: does any kernel read workspace bytes nobody wrote?  The workspace is filled with a poison pattern before every forward."""
+import os, subprocess, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = r"""
+import os, sys, torch, hashlib
+sys.path.insert(0, %r)
+from uformer_amd import model as um, spec
+cfg = spec.arch_config("Uformer_B", img_size=256); sd = spec.synth_state_dict(cfg, 1234)
+x = spec.synth_input(16, 256, 256, 1234).cuda()
+m = um.Uformer(img_size=256, embed_dim=32, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=True, compute_dtype=torch.bfloat16).eval(); m.load_state_dict(sd); m = m.cuda()
+hs = {}
+with torch.no_grad():
+    y = m(x)     # allocates the workspace
+    for poison in (0xFF, 0x00, 0xFF, 0x7F, 0xFF, 0x00):
+        for ws in m._ws.values():
+            ws.fill_(poison)
+        torch.cuda.synchronize()
+        y = m(x)
+        h = hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:12]
+        print(os.environ.get("TAG"), "poison %%02x ->" %% poison, h, "finite" if torch.isfinite(y).all() else "NOT FINITE")
+""" % R
+for tag, env in (("v2 2 streams", {}), ("v1 2 streams", {"UF_INPUT_PROJ_V1": "1"}), ("v2 1 stream", {"UF_STREAMS": "1"}), ("v1 1 stream", {"UF_STREAMS": "1", "UF_INPUT_PROJ_V1": "1"}),
+                 ("v2 2 streams out v1", {"UF_OUTPUT_PROJ_V1": "1"}), ("v2 2 streams mc0 lib", {"UFORMER_HIP_LIB": R + "/ab/mc0new/libuformer_hip.so"})):
+    if "UFORMER_HIP_LIB" in env and not os.path.exists(env["UFORMER_HIP_LIB"]):
+        continue
+    subprocess.call([sys.executable, "-c", code], env=dict(os.environ, TAG=tag, **env))

@@ -388,9 +388,9 @@ def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
         bias = torch.randn(E, generator=gen) * 0.1
         from uformer_amd import packing
         w27 = packing.pack_input_proj(w).cuda()
-        monkeypatch.setenv("UF_INPUT_PROJ_V1", "1")
+        monkeypatch.setenv("UF_INPUT_PROJ_V2", "0")
         ref = ops.input_proj(img, w27, bias.cuda())
-        monkeypatch.setenv("UF_INPUT_PROJ_V1", "0")
+        monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")                   # opt-in form (see uf_input_proj_fwd: exact in isolation, not the default)
         got = ops.input_proj(img, w27, bias.cuda())
         assert torch.equal(got, ref), f"input_proj E={E}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
         ora = O.input_proj(img.cpu(), {"input_proj.proj.0.weight": w, "input_proj.proj.0.bias": bias})

@@ -391,10 +391,21 @@ template <int EG>                                   // lanes per pixel = E / 4 (
 __global__ __launch_bounds__(256, (UF_IP2_DBG & 1) ? 1 : 4) void input_proj2_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ld_o, int B, int H, int W) {
     constexpr int CIN = 3, E = EG * 4, SL = 8, NSTRIP = 64 / EG, TW = NSTRIP * SL, RS = TW + 4;     // row stride in floats (16-byte multiple; index j = pixel x0 - 1 + j)
+#if (UF_IP2_DBG & 32)
+    extern __shared__ __attribute__((aligned(16))) char dyn_ip2[];
+    float (*Is)[6][RS] = reinterpret_cast<float (*)[6][RS]>(dyn_ip2);
+    float* Ws = reinterpret_cast<float*>(dyn_ip2 + CIN * 6 * RS * 4);
+#else
     __shared__ __attribute__((aligned(16))) float Is[CIN][6][RS];
     __shared__ __attribute__((aligned(16))) float Ws[27 * E];
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * 4, b = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (UF_IP2_DBG & 16) {                              // 1-D launch: x = tile column fastest, then tile row, then image
+        const int tx_n = (W + TW - 1) / TW, ty_n = (H + 3) / 4;
+        bx = (int)blockIdx.x % tx_n; by = ((int)blockIdx.x / tx_n) % ty_n; bz = (int)blockIdx.x / (tx_n * ty_n);
+    }
+    const int x0 = bx * TW, y0 = by * 4, b = bz;
     for (int i = tid; i < CIN * 6 * (TW + 2); i += 256) {
         const int j = i % (TW + 2), r = (i / (TW + 2)) % 6, ci = i / ((TW + 2) * 6);
         const int ix = x0 - 1 + j, iy = y0 - 1 + r;
@@ -404,6 +415,7 @@ __global__ __launch_bounds__(256, (UF_IP2_DBG & 1) ? 1 : 4) void input_proj2_ker
     }
     if (!(UF_IP2_DBG & 2)) { for (int i = tid; i < 27 * E; i += 256) Ws[i] = w27[i]; }
     if (UF_IP2_DBG & 4) { for (int i = tid; i < CIN * 6 * RS; i += 256) if (i % RS >= TW + 2) (&Is[0][0][0])[i] = 0.f; }
+    if (UF_IP2_DBG & 64) { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
     __syncthreads();
     const int e = (lane % EG) * 4, strip = lane / EG;
     const int yh = y0 + wave, xs = x0 + strip * SL;
@@ -436,6 +448,7 @@ __global__ __launch_bounds__(256, (UF_IP2_DBG & 1) ? 1 : 4) void input_proj2_ker
         for (int i = 0; i < 4; ++i) a[i] = a[i] >= 0.f ? a[i] : 0.01f * a[i];
         *reinterpret_cast<f32x4*>(out + (size_t)((b * H + yh) * W + xs + q) * ld_o + e) = a;
     }
+    if (UF_IP2_DBG & 8) __threadfence();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -783,11 +796,21 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
     UF_REQUIRE(H <= 65535 && B <= 65535, UF_ERR_SHAPE, "uf_input_proj_fwd: H=%d B=%d exceed the launch grid", H, B);
     const unsigned nx = (unsigned)((W + IP_PX - 1) / IP_PX) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
-    const char* e1 = getenv("UF_INPUT_PROJ_V1");                           // A/B switch / bit-identity test: the first (global-load) form
-    const bool v1 = e1 && e1[0] != '0';
+    // The LDS-staged second form (input_proj2_kernel: 107 -> 44 us at 16 x 256 x 256, bit-identical to this form in isolation and in the one-stream model)
+    // is OPT-IN (UF_INPUT_PROJ_V2=1): with the model's default two half-batch streams -- i.e. two hardware queues -- the blocks that consume its output
+    // read STALE rows (whatever the workspace held before) for the last image(s) of a side-stream part whenever the workspace content changed since the
+    // previous forward: the first forward of a process, or a refilled workspace (scripts/r04_dbg3.py ... r04_dbg5.py, gpurun_out/r04_dbg*.txt: wrong
+    // results in 2 of 10 ... 10 of 10 forwards; never with this first form, never with one stream, never with GPU_MAX_HW_QUEUES=1; independent of static /
+    // dynamic LDS, of where the weights are read, of the register bound; a trailing __threadfence() lowers the rate and does not remove it).  The
+    // mechanism is not understood, so the form that has been exact for four rounds stays the default.
+    const char* e2 = getenv("UF_INPUT_PROJ_V2");
+    const bool v1 = !(e2 && e2[0] == '1');
     if (!v1 && Cin == 3 && (E == 32 || E == 16) && (H + 3) / 4 <= 65535) {
-        if (E == 32) hipLaunchKernelGGL(input_proj2_kernel<8>, dim3((W + 63) / 64, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
-        else hipLaunchKernelGGL(input_proj2_kernel<4>, dim3((W + 127) / 128, (H + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
+        const dim3 g32 = (UF_IP2_DBG & 16) ? dim3(((W + 63) / 64) * ((H + 3) / 4) * B) : dim3((W + 63) / 64, (H + 3) / 4, B);
+        const dim3 g16 = (UF_IP2_DBG & 16) ? dim3(((W + 127) / 128) * ((H + 3) / 4) * B) : dim3((W + 127) / 128, (H + 3) / 4, B);
+        const int dyn = (UF_IP2_DBG & 32) ? 16384 : 0;
+        if (E == 32) hipLaunchKernelGGL(input_proj2_kernel<8>, g32, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
+        else hipLaunchKernelGGL(input_proj2_kernel<4>, g16, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
         return check_launch("input_proj");
     }
     hipLaunchKernelGGL(input_proj_kernel, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
