@@ -19,7 +19,5 @@ with torch.no_grad():
         hs[h] = hs.get(h, 0) + 1
 print(os.environ.get("TAG"), hs)
 """ % R
-for tag, env in (("v2 dynamic LDS", {"UFORMER_HIP_LIB": R + "/ab/ip34/libuformer_hip.so"}), ("v2 slower (sleep)", {"UFORMER_HIP_LIB": R + "/ab/ip66/libuformer_hip.so"}),
-                 ("v2 default again", {"UFORMER_HIP_LIB": R + "/ab/ip2/libuformer_hip.so"}), ("v2 default, HIP_LAUNCH_BLOCKING-free but GPU_MAX_HW_QUEUES=1", {"GPU_MAX_HW_QUEUES": "1"}),
-                 ("v2 + threadfence, run 2", {"UFORMER_HIP_LIB": R + "/ab/ip10/libuformer_hip.so"})):
+for tag, env in (("default", {}), ("default again", {}), ("3 streams", {"UF_STREAMS": "3"}), ("one tile per workgroup", {"UF_LEFF2_PERSIST": "0"})):
     subprocess.call([sys.executable, "-c", code], env=dict(os.environ, TAG=tag, **env))

@@ -25,6 +25,7 @@ struct Leff2Params {
     float* x; int ld;               // residual stream rows, in place
     const float* drop;              // training: per-image DropPath scale of the branch (model.py:987) or NULL
     int B, H, W;
+    int n_tiles;                // B * (H / 8) * (W / 8): a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (persistent launch: gridDim.x < n_tiles)
     unsigned long long* tbuf;   // optional per-role cycle totals of sampled blocks (uf_debug_set_tbuf)
 };
 
@@ -120,9 +121,22 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
     const bool producer = wave < NP;
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_x = p.W / TW, tiles_y = p.H / TH;
-    const int bt = xcd_tile(blockIdx.x, gridDim.x);
-    const int b = bt / (tiles_x * tiles_y), tr = bt - b * (tiles_x * tiles_y);
-    const int y0 = (tr / tiles_x) * TH, x0 = (tr % tiles_x) * TW;
+    // Persistent walk (round 4): this workgroup owns tiles v = blockIdx.x + k * gridDim.x (k = 0 .. nk - 1) of the XCD-aware order, and the interval
+    // stream -- DMA ring, operand tiles, one barrier per interval -- runs ACROSS its tiles: flattened interval m = k * NIT + i.  The DMA of the
+    // next tile's first intervals flies under the last intervals of the current one and the consumers' epilogue (with the residual rows requested an
+    // interval ahead where registers allow) runs beside the producers' first stencil of the next tile, instead of a drained pipeline, a prologue that
+    // waits for its first halo tile and an exposed read-modify-write per tile (29-50 % of a workgroup's life at C <= 128: census and role stamps
+    // of profiles/r04_run2.txt).  gridDim.x = n_tiles reproduces the one-tile-per-workgroup launch.
+    const int G = (int)gridDim.x;
+    const int nk = (p.n_tiles - (int)blockIdx.x + G - 1) / G;
+    const int NTOT = nk * NIT;
+    const int bt = xcd_tile(blockIdx.x, p.n_tiles);               // first tile: census / stamp index
+    auto tile_coords = [&](int k, int& b, int& y0, int& x0) {
+        const int t = xcd_tile((int)blockIdx.x + k * G, p.n_tiles);
+        b = t / (tiles_x * tiles_y);
+        const int tr = t - b * (tiles_x * tiles_y);
+        y0 = (tr / tiles_x) * TH; x0 = (tr % tiles_x) * TW;
+    };
     const T* W2 = reinterpret_cast<const T*>(p.W2);
 
     Census census; census.begin();
@@ -130,30 +144,38 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
         // ------------------------------ producers: DMA prefetch + stencil ---------------------------
         const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the dynamic region
         const unsigned lds_dummy = lds0 + NBUF * BUFB + 2 * AT_BYTES;
-        // buffer descriptor over this image's h1: raw, 32-bit offsets, out-of-range lanes read 0 = the conv's zero padding
-        const char* img = reinterpret_cast<const char*>(p.h1) + (size_t)b * p.H * p.W * HID * SZ;
-        const unsigned long long ia = (unsigned long long)(uintptr_t)img;
-        const u32x4 rsrc = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ia), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ia >> 32)) & 0xffffu,
-                            (unsigned)__builtin_amdgcn_readfirstlane(p.H * p.W * HID * SZ), 0x00020000u};
-        // this lane's source offset in each of the wave's DMA slots (slot s covers instruction wave + s*NP of the interval)
+        // buffer descriptor over ONE image of h1 (raw, 32-bit offsets, out-of-range lanes read 0 = the conv's zero padding) and this lane's source
+        // offset in each of the wave's DMA slots (slot s covers instruction wave + s*NP of the interval): both follow the tile the ISSUE stream is in
+        u32x4 rsrc = {0u, 0u, (unsigned)__builtin_amdgcn_readfirstlane(p.H * p.W * HID * SZ), 0x00020000u};
         unsigned voff[NS];
+        int issue_k = -1;
+        auto set_issue_tile = [&](int k) {
+            int b, y0, x0;
+            tile_coords(k, b, y0, x0);
+            const unsigned long long ia = (unsigned long long)(uintptr_t)(reinterpret_cast<const char*>(p.h1) + (size_t)b * p.H * p.W * HID * SZ);
+            rsrc[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ia);
+            rsrc[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ia >> 32)) & 0xffffu;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int idx = wave + s * NP;
-            voff[s] = 0xffffff00u;                              // out of range -> zeros
-            if (idx < NHI) {
-                const int g = idx / NHG, q = (idx - g * NHG) * 64 + lane;    // piece q of group g's halo tile
-                const int hp = q / CPP, part = q - hp * CPP;
-                const int hy = hp / HW_, hx = hp - hy * HW_;
-                const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-                // MFMA stencil: slot `part` of a halo pixel holds its 16-byte piece part ^ (hx & 6) -- the placement that makes the B-fragment
-                // reads (16 lanes = 16 pixels at a 128-byte stride) conflict-free; a lane fetches the piece that belongs where it lands
-                const int piece = MC ? (part ^ (hx & 6)) : part;
-                if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) voff[s] = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + piece * 16);
+            for (int s = 0; s < NS; ++s) {
+                const int idx = wave + s * NP;
+                voff[s] = 0xffffff00u;                              // out of range -> zeros
+                if (idx < NHI) {
+                    const int g = idx / NHG, q = (idx - g * NHG) * 64 + lane;    // piece q of group g's halo tile
+                    const int hp = q / CPP, part = q - hp * CPP;
+                    const int hy = hp / HW_, hx = hp - hy * HW_;
+                    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+                    // MFMA stencil: slot `part` of a halo pixel holds its 16-byte piece part ^ (hx & 6) -- the placement that makes the B-fragment
+                    // reads (16 lanes = 16 pixels at a 128-byte stride) conflict-free; a lane fetches the piece that belongs where it lands
+                    const int piece = MC ? (part ^ (hx & 6)) : part;
+                    if (hp < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) voff[s] = (unsigned)(((iy * p.W + ix) * HID + g * KCW) * SZ + piece * 16);
+                }
             }
-        }
-        auto issue = [&](int it) {                              // all DMA of interval `it` into ring slot it % NBUF
-            const unsigned slot = lds0 + (unsigned)(it % NBUF) * BUFB;
+            issue_k = k;
+        };
+        auto issue = [&](int m) {                               // all DMA of flattened interval m into ring slot m % NBUF
+            const int k = m / NIT, it = m - k * NIT;
+            if (k != issue_k) set_issue_tile(k);
+            const unsigned slot = lds0 + (unsigned)(m % NBUF) * BUFB;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int idx = wave + s * NP;                  // wave-uniform
@@ -191,14 +213,14 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
         }
 #pragma unroll
         for (int it = 0; it < NBUF - 1; ++it)
-            if (it < NIT) issue(it);
+            if (it < NTOT) issue(it);
         wait_dma<0>();
         lds_barrier();                                                          // B0: intervals 0 .. NBUF-2 staged
         unsigned long long tw = 0, tbar = 0, t0 = __builtin_readcyclecounter(), t1;
 #pragma unroll 1
-        for (int i = 0; i <= NIT; ++i) {
-            if (i + NBUF - 1 < NIT) issue(i + NBUF - 1);        // ring slot last read in iteration i-1
-            if (i < NIT) {
+        for (int i = 0; i <= NTOT; ++i) {                       // i = flattened interval
+            if (i + NBUF - 1 < NTOT) issue(i + NBUF - 1);       // ring slot last read in iteration i-1
+            if (i < NTOT) {
                 const char* Hs = Ring + (i % NBUF) * BUFB + grp * HGB;
                 const float* Wl = reinterpret_cast<const float*>(Ring + (i % NBUF) * BUFB + NPG * HGB) + grp * KCW;
                 char* At = At0 + (i & 1) * AT_BYTES + grp * KCW * SZ;
@@ -276,7 +298,7 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
             }
             t1 = __builtin_readcyclecounter(); tw += t1 - t0; t0 = t1;
             // interval i+1 must have landed before anyone passes the barrier; later intervals stay in flight
-            if (NBUF >= 3 && i + NBUF - 1 < NIT) wait_dma<(NBUF - 2) * NS>(); else wait_dma<0>();
+            if (NBUF >= 3 && i + NBUF - 1 < NTOT) wait_dma<(NBUF - 2) * NS>(); else wait_dma<0>();
             lds_barrier();
             t1 = __builtin_readcyclecounter(); tbar += t1 - t0; t0 = t1;
         }
@@ -318,19 +340,39 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
 #pragma unroll
         for (int j = 0; j < TMW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // iteration j: MFMAs of interval j-1 (operand tile written by the producers in iteration j-1), sub-chunk by sub-chunk;
+    // iteration j: MFMAs of flattened interval j-1 (operand tile written by the producers in iteration j-1), sub-chunk by sub-chunk;
     // the W2 fragments of the next sub-chunk are requested as soon as the registers are free -- across the barrier between
-    // intervals, so their L2 round trip hides under the wait for the stencil
+    // intervals, so their L2 round trip hides under the wait for the stencil.  After the last interval of a tile: epilogue
+    // (+ bias + residual, in place on the f32 stream, model.py:987), accumulators back to zero.  Where the registers allow
+    // (C <= 128) the residual rows of a tile are requested at the start of its last interval.
+    constexpr bool XPRE = SZ == 2 && TNW * TMW <= 4;        // C <= 64 (16 registers); at C = 128 the 32 registers spill under the 80-register bound
+    f32x4 xres[XPRE ? TNW : 1][XPRE ? TMW : 1];
+    auto x_ptr = [&](int b, int y0, int x0, int i, int j) -> float* {
+        const int n = (wn * TNW + i) * 16 + fg * 4;
+        const int pm = (wm * TMW + j) * 16 + fr;
+        return p.x + ((size_t)(b * p.H + y0 + (pm >> 3)) * p.W + x0 + (pm & 7)) * p.ld + n;
+    };
     w2_issue(0);
     lds_barrier();                                         // B0
     unsigned long long ctw = 0, ctbar = 0, ct0 = __builtin_readcyclecounter(), ct1;
 #pragma unroll 1
-    for (int j = 0; j <= NIT; ++j) {
+    for (int j = 0; j <= NTOT; ++j) {
         if (j >= 1) {
-            const char* At = At0 + ((j - 1) & 1) * AT_BYTES;
+            const int m = j - 1, k = m / NIT, it = m - k * NIT;
+            int tb = 0, ty0 = 0, tx0 = 0;
+            if (it == NIT - 1) {
+                tile_coords(k, tb, ty0, tx0);
+                if constexpr (XPRE) {
+#pragma unroll
+                    for (int i = 0; i < TNW; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TMW; ++jj) xres[i][jj] = *reinterpret_cast<const f32x4*>(x_ptr(tb, ty0, tx0, i, jj));
+                }
+            }
+            const char* At = At0 + (m & 1) * AT_BYTES;
 #pragma unroll
             for (int g = 0; g < NPG; ++g) {
-                const int sub = (j - 1) * NPG + g;
+                const int sub = it * NPG + g;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     if constexpr (WKS == 1) w2_load(sub, ks, 0);
@@ -346,7 +388,23 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (sub + 1 < NIT * NPG) w2_issue(sub + 1);
+                else if (j < NTOT) w2_issue(0);           // first sub-chunk of the next tile
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it == NIT - 1) {
+                const float dscale = p.drop ? p.drop[tb] : 1.0f;
+#pragma unroll
+                for (int i = 0; i < TNW; ++i) {
+                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + (wn * TNW + i) * 16 + fg * 4);
+#pragma unroll
+                    for (int jj = 0; jj < TMW; ++jj) {
+                        float* xp = x_ptr(tb, ty0, tx0, i, jj);
+                        f32x4 r;
+                        if constexpr (XPRE) r = xres[i][jj]; else r = *reinterpret_cast<const f32x4*>(xp);
+                        *reinterpret_cast<f32x4*>(xp) = r + (acc[i][jj] + b2) * dscale;
+                        acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
             }
         }
         ct1 = __builtin_readcyclecounter(); ctw += ct1 - ct0; ct0 = ct1;
@@ -354,21 +412,6 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
         ct1 = __builtin_readcyclecounter(); ctbar += ct1 - ct0; ct0 = ct1;
     }
     if (p.tbuf && lane == 0 && (bt & 63) == 0) { p.tbuf[((bt >> 6) * 16 + wave) * 4] = ctw; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 1] = ctbar; p.tbuf[((bt >> 6) * 16 + wave) * 4 + 2] = 0; }
-
-    // ---- epilogue: + bias + residual, in place on the f32 stream (model.py:987) ----
-    const float dscale = p.drop ? p.drop[b] : 1.0f;
-#pragma unroll
-    for (int i = 0; i < TNW; ++i) {
-        const int n = (wn * TNW + i) * 16 + fg * 4;
-        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + n);
-#pragma unroll
-        for (int j = 0; j < TMW; ++j) {
-            const int pm = (wm * TMW + j) * 16 + fr;
-            const int ty = pm >> 3, tx = pm & 7;
-            float* xp = p.x + ((size_t)(b * p.H + y0 + ty) * p.W + x0 + tx) * p.ld + n;
-            *reinterpret_cast<f32x4*>(xp) = *reinterpret_cast<const f32x4*>(xp) + (acc[i][j] + b2) * dscale;
-        }
-    }
     if (cw == 0 && lane == 0) {   // census entry written by the first consumer thread (thread 0 is a producer and has returned)
         Census c2 = census;
         if (p.tbuf) { unsigned long long* o = p.tbuf + 65536 + (size_t)bt * 8; o[0] = c2.t0; o[1] = __builtin_readcyclecounter(); o[2] = c2.r0; o[3] = wall_clock64();
@@ -390,7 +433,19 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
     if (timing_enabled()) snprintf(name, sizeof(name), "leff2_%s_c%d_np%d_nc%d %lldx%dx%d", TypeName<T>::s, C, PW * NPG, NC, M, C, 4 * C);
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.H / 8) * (p.W / 8))), dim3((PW * NPG + NC) * 64), smem, st, p);
+        // persistent launch: at most `resident` workgroups (what a CU holds of this variant x 256 CUs), every one walking ceil(n_tiles / grid) tiles;
+        // the grid is a multiple of 8 (XCD-aware tile order) and divides the tiles as evenly as it can.  UF_LEFF2_PERSIST=0: one tile per workgroup.
+        static const bool persist = !(getenv("UF_LEFF2_PERSIST") && getenv("UF_LEFF2_PERSIST")[0] == '0');
+        constexpr int waves = PW * NPG + NC;
+        constexpr int by_lds = (160 * 1024) / smem, by_waves = 32 / waves, by_regs = (WPS * 4) / waves > 0 ? (WPS * 4) / waves : 1;
+        constexpr int per_cu = by_lds < by_waves ? (by_lds < by_regs ? by_lds : by_regs) : (by_waves < by_regs ? by_waves : by_regs);
+        const int resident = 256 * (per_cu < 1 ? 1 : per_cu);
+        int grid = p.n_tiles;
+        if (persist && p.n_tiles > resident) {
+            const int rounds = (p.n_tiles + resident - 1) / resident;
+            grid = ((p.n_tiles + rounds - 1) / rounds + 7) / 8 * 8;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(waves * 64), smem, st, p);
     }
     return check_launch("leff2");
 }
@@ -467,6 +522,7 @@ int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* 
     Leff2Params p{};
     p.tbuf = debug_get_tbuf();
     p.h1 = h1; p.w9 = w9; p.bdw = bdw; p.W2 = W2; p.b2 = b2; p.x = x; p.ld = ld; p.B = B; p.H = H; p.W = W; p.drop = drop;
+    p.n_tiles = B * (H / 8) * (W / 8);
     if (dtype == UF_BF16) return launch_t<bf16>(p, C, st);
     if (dtype == UF_F16) return launch_t<f16>(p, C, st);
     if (dtype == UF_F32) return launch_t<float>(p, C, st);
