@@ -18,18 +18,18 @@ src, dst = sys.argv[1], sys.argv[2]
 
 
 def symbol(kernel):
-    m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)>", kernel)
+    m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)(?:, \d+)?>", kernel)                   # <T, C, NT[, LR]>
     if m:
         return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
-    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)>", kernel)      # <T, C, NPG, NC, NBUF, WPS>
+    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", kernel)      # <T, C, NPG, NC, NBUF, WPS[, PW]>
     if m:
-        return f"leff2_bf16_c{m.group(1)}_np{4 * int(m.group(2))}_nc{m.group(3)}"
-    m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)>", kernel)
+        return f"leff2_bf16_c{m.group(1)}_np{int(m.group(6) or 4) * int(m.group(2))}_nc{m.group(3)}"
+    m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)(?:, (true|false))?>", kernel)     # <T, BN, WGM, WGN, AL, EP[, DMA]>
     if m:
-        return f"gemm_bf16_bn{m.group(1)}_a{m.group(2)}_e{m.group(3)}"
-    if "input_proj_kernel" in kernel:
+        return f"gemm_bf16_bn{m.group(1)}_a{m.group(2)}_e{m.group(3)}" + ("_dma" if m.group(4) == "true" else "")
+    if "input_proj_kernel" in kernel or "input_proj2_kernel" in kernel:
         return "input_proj"
-    if "output_proj_kernel" in kernel:
+    if "output_proj_kernel" in kernel or "output_proj2_kernel" in kernel:
         return "output_proj"
     return None
 
@@ -51,7 +51,7 @@ def first(*names):
         if os.path.exists(f"{src}/{n}"):
             return f"{src}/{n}"
     raise SystemExit(f"none of {names} under {src}")
-fetch, write = load(first("pmcC_pmc.csv", "r03_final_pmcC.csv", "r02_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r03_final_pmcD.csv", "r02_final_pmcD.csv"), "WRITE_SIZE")
+fetch, write = load(first("pmcC_pmc.csv", "r04_final_pmcC.csv", "r03_final_pmcC.csv", "r02_final_pmcC.csv"), "FETCH_SIZE"), load(first("pmcD_pmc.csv", "r04_final_pmcD.csv", "r03_final_pmcD.csv", "r02_final_pmcD.csv"), "WRITE_SIZE")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_sha: the stamp bench.py checks before it quotes these numbers)
 out = {}
@@ -59,7 +59,7 @@ for s in sorted(fetch):
     f, n = fetch[s]
     w = write.get(s, (0.0, 0))[0]
     out[s] = {"fetch_bytes_per_launch": 2.0 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2.0 * f + w, "dispatches_profiled": n}
-json.dump({"kernel_source_sha": bench.kernel_source_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-modes --no-train-mode (UF_STREAMS=1); "
+json.dump({"kernel_source_sha": bench.kernel_source_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-modes --no-train-mode --no-720p (UF_STREAMS=1); "
                      "FETCH_SIZE x2 (gfx950 wide-read correction), KiB -> bytes; average over the launches of a symbol",
            "kernels": out}, open(dst, "w"), indent=1)
 for s, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

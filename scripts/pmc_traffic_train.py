@@ -18,14 +18,14 @@ STEPS = 2
 def symbol(kernel):
     """rocprofv3 kernel name -> (timing symbol of bench.py's train table, counts as a launch of that symbol?)"""
     k = kernel
-    m = re.search(r"linear_wgrad2?_kernel<uf::(\w+)", k)
+    m = re.search(r"linear_wgrad[23]?_kernel<uf::(\w+)", k)
     if m:
         return f"linear_wgrad_{m.group(1)}", True
     if "column_sum" in k:
         return "wgrad_second_stage", True                         # fixed-order sums of the chunk partials (outside the timing scope of linear_wgrad_*)
-    m = re.search(r"gemm_kernel<uf::(\w+), (\d+), \d+, \d+, (\d+), (\d+)>", k)
+    m = re.search(r"gemm_kernel<uf::(\w+), (\d+), \d+, \d+, (\d+), (\d+)(?:, (true|false))?>", k)
     if m:
-        return f"gemm_{m.group(1)}_bn{m.group(2)}_a{m.group(3)}_e{m.group(4)}", True
+        return f"gemm_{m.group(1)}_bn{m.group(2)}_a{m.group(3)}_e{m.group(4)}" + ("_dma" if m.group(5) == "true" else ""), True
     m = re.search(r"window_attn_bwd_kernel<uf::(\w+)", k)
     if m:
         return f"window_attn_bwd_{m.group(1)}", True

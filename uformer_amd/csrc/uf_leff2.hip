@@ -434,8 +434,14 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
     {
         ScopedTimer tm(name, 2.0 * M * C * 4 * C + 18.0 * M * 4 * C, (double)M * 4 * C * SZ + (double)M * C * 8, st);
         // persistent launch: at most `resident` workgroups (what a CU holds of this variant x 256 CUs), every one walking ceil(n_tiles / grid) tiles;
-        // the grid is a multiple of 8 (XCD-aware tile order) and divides the tiles as evenly as it can.  UF_LEFF2_PERSIST=0: one tile per workgroup.
-        static const bool persist = !(getenv("UF_LEFF2_PERSIST") && getenv("UF_LEFF2_PERSIST")[0] == '0');
+        // the grid is a multiple of 8 (XCD-aware tile order) and divides the tiles as evenly as it can.  Measured per stage against one tile per
+        // workgroup (profiles/r04_run6.txt, ms per step): C = 32 0.163 -> 0.129, C = 256 (dec1) 0.653 -> 0.621, C = 128 with 1024 tiles 0.339 -> 0.329,
+        // but C = 64 0.263 -> 0.267 / 0.137 -> 0.137 and C = 128 with 4096 tiles 0.308 -> 0.332 (three workgroups per CU already cover each other's
+        // prologue and epilogue there, and an even split leaves 688 of 768 slots filled) -- so the walk is used where it paid.
+        // UF_LEFF2_PERSIST=0 / =1: never / wherever there are more tiles than resident workgroups.
+        static const char* pe = getenv("UF_LEFF2_PERSIST");
+        const bool pays = C <= 32 || C >= 256 || (C == 128 && p.n_tiles <= 1024);
+        const bool persist = pe ? pe[0] != '0' : pays;
         constexpr int waves = PW * NPG + NC;
         constexpr int by_lds = (160 * 1024) / smem, by_waves = 32 / waves, by_regs = (WPS * 4) / waves > 0 ? (WPS * 4) / waves : 1;
         constexpr int per_cu = by_lds < by_waves ? (by_lds < by_regs ? by_lds : by_regs) : (by_waves < by_regs ? by_waves : by_regs);
