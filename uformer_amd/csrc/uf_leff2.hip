@@ -50,6 +50,9 @@ constexpr int KCW = 64;  // hidden channels one producer group (4 waves) convolv
 #ifndef UF_MCONV
 #define UF_MCONV 1
 #endif
+#ifndef UF_LEFF2_CP_DEFAULT
+#define UF_LEFF2_CP_DEFAULT false
+#endif
 template <typename T> __device__ __forceinline__ unsigned cvt16(float f);
 template <> __device__ __forceinline__ unsigned cvt16<bf16>(float f) { return f2bf(f); }
 template <> __device__ __forceinline__ unsigned cvt16<f16>(float f) { return f2h(f); }
@@ -73,6 +76,46 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
+// One job of the MFMA stencil (UF_MCONV 1 / 2): pixel tiles [pt0, pt0 + NPT) of the 16-channel group gq of an interval -> operand tile.
+// Hs: the group's halo tile in the ring slot, Wl: its tap table [10][KC] f32, At: the operand tile [64][KC] (row stride SAT).
+template <typename T, int MCV, int NPT, int KC, int SAT, int HROW>
+__device__ __forceinline__ void mconv_job(const char* Hs, const float* Wl, char* At, int gq, int pt0, const int* boff, const unsigned* msk, unsigned hshift, int fr, int fg) {
+    constexpr int NKS = MCV == 2 ? 9 : 5;
+    const float* wc = Wl + gq * 16 + fr;                  // this lane's channel in the tap table
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(Wl + 9 * KC + gq * 16 + fg * 4);
+    float wt[NKS];                                        // the lane's tap of every k-step, requested up front (one LDS round trip)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) wt[ks] = wc[(MCV == 2 ? ks : ((2 * ks + (fg >> 1)) < 9 ? 2 * ks + (fg >> 1) : 8)) * KC];
+    f32x4 cacc[NPT];
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) cacc[pt] = bias4;
+    const char* Hp = Hs + pt0 * HROW;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        unsigned v16;
+        if constexpr (MCV == 2) {                         // k-step = tap ks; lane groups 0,1: hi part, 2,3: lo part
+            const unsigned hi = cvt16<T>(wt[ks]);
+            v16 = (fg >> 1) ? cvt16<T>(wt[ks] - back16<T>(hi)) : hi;
+        } else {                                          // k-step = taps 2ks (lane groups 0,1) and 2ks+1 (2,3); tap 9 = padding
+            v16 = (2 * ks + (fg >> 1)) < 9 ? cvt16<T>(wt[ks]) : 0u;
+        }
+        const unsigned sh = v16 << hshift;
+        Frag<T> af;                                       // block-diagonal weight fragment of this k-step: one non-zero 16-bit slot per lane
+        af.v = u32x4{sh & msk[0], sh & msk[1], sh & msk[2], sh & msk[3]};
+#pragma unroll
+        for (int pt = 0; pt < NPT; ++pt) {
+            Frag<T> bf;
+            bf.v = *reinterpret_cast<const u32x4*>(Hp + boff[ks] + pt * HROW);
+            mma16(cacc[pt], af, bf);                      // weights as A: lane = pixel fr, channels 4 fg .. 4 fg + 3
+        }
+    }
+#pragma unroll
+    for (int pt = 0; pt < NPT; ++pt) {
+        gelu4<T>(cacc[pt]);
+        store4(reinterpret_cast<T*>(At + ((pt0 + pt) * 16 + fr) * SAT) + gq * 16 + fg * 4, cacc[pt]);
+    }
+}
+
 // Wave-specialised kernel.  4*NPG PRODUCER waves (depthwise stencil + GELU on the VALU, and the LDS-DMA prefetch of the halo /
 // tap tiles) and NC CONSUMER waves (W2 fragments L2 -> registers, MFMAs, epilogue).  The hardware spreads the waves of a
 // workgroup over the 4 SIMDs, and the VALU and matrix pipes of a SIMD run concurrently for different waves, so the stencil
@@ -81,12 +124,16 @@ __device__ __forceinline__ void put8(float* p, const float* f) {
 // (<= 256 tiles, or C = 512 whose consumers need the registers): two stencil waves per SIMD hide each other's LDS latency.
 // Halo / tap tiles: NBUF-deep ring in LDS filled by DMA NBUF-1 intervals ahead; operand tile: double buffered; one barrier
 // per interval.
-template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4>
+// CP (round 4): pixel tiles (of the 4 of an interval) whose stencil the CONSUMER waves take over, one (16-channel group, pixel tile) job per consumer
+// wave: 1 with 4 consumers, 2 with 8.  The role stamps (profiles/r04_run2.txt) show the producers as the critical path of an interval (a chain of
+// ~2 K cycles) with the consumers parked 50-76 % of the time at C <= 256; a consumer's job runs behind its MFMAs of the previous interval.
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4, int CP = 0>
 __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const Leff2Params p) {
     constexpr int NP = PW * NPG;                  // producer waves: PW (4 or 8) per 64-channel group of the interval
     constexpr int MC = sizeof(T) == 2 ? UF_MCONV : 0;   // depthwise 3x3 on the MFMA (2-byte operand types), see UF_MCONV
     static_assert(PW == 4 || (PW == 8 && MC != 0), "8 producer waves per group: MFMA stencil only (two pixel tiles per wave)");
-    constexpr int PTW = 16 / PW;                  // pixel tiles (16 pixels) per producer wave
+    static_assert(CP == 0 || (MC != 0 && PW == 4 && NPG == 1 && NC == 4 * CP), "consumer stencil jobs: MFMA stencil, 4 producers, one job per consumer wave");
+    constexpr int PTW = 16 / PW - CP;             // pixel tiles (16 pixels) per producer wave
     constexpr int SR = 2;                         // rows of the column strip one producer thread convolves
     constexpr int SZ = sizeof(T);
     constexpr int TH = 8, TW = 8, BM = 64;
@@ -139,6 +186,21 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
     };
     const T* W2 = reinterpret_cast<const T*>(p.W2);
 
+    // MFMA stencil constants of a wave: the lane's non-zero slot of the block-diagonal weight fragments and the byte offsets of its B fragments
+    // (pixel tile 0; tile pt adds two halo rows) per k-step, for the wave's 16-channel group gq
+    const unsigned hshift = (fr & 1) * 16;
+    unsigned msk[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) msk[d] = ((fg & 1) == (fr >> 3) && d == ((fr & 7) >> 1)) ? 0xffffffffu : 0u;
+    const int gq = (producer ? wave : wave - NP) & 3;
+    int boff[MC == 2 ? 9 : 5];
+#pragma unroll
+    for (int ks = 0; ks < (MC == 2 ? 9 : 5); ++ks) {
+        int tap = MC == 2 ? ks : 2 * ks + (fg >> 1);
+        tap = tap < 9 ? tap : 8;
+        const int hy = (fr >> 3) + tap / 3, hx = (fr & 7) + tap % 3;
+        boff[ks] = ((hy * HW_ + hx) * 8 + ((gq * 2 + (fg & 1)) ^ (hx & 6))) * 16;
+    }
     Census census; census.begin();
     if (producer) {
         // ------------------------------ producers: DMA prefetch + stencil ---------------------------
@@ -196,21 +258,7 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
         const int grp = wave / PW;                              // producer group
         const int gt = tid & 255;                               // thread index within the group (VALU stencil)
         const int cvec = gt & 7, sx = (gt >> 3) & 7, sy0 = (gt >> 6) * SR;
-        // MFMA stencil: the wave's 16-channel group, the lane's non-zero slot of the block-diagonal weight fragments, and the byte offsets
-        // of its B fragments (pixel tile 0; tile pt adds two halo rows) per k-step
-        const int gq = wave & 3, pt0 = ((wave % PW) >> 2) * PTW;   // 16-channel group, first pixel tile
-        const unsigned hshift = (fr & 1) * 16;
-        unsigned msk[4];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) msk[d] = ((fg & 1) == (fr >> 3) && d == ((fr & 7) >> 1)) ? 0xffffffffu : 0u;
-        int boff[MC == 2 ? 9 : 5];
-#pragma unroll
-        for (int ks = 0; ks < (MC == 2 ? 9 : 5); ++ks) {
-            int tap = MC == 2 ? ks : 2 * ks + (fg >> 1);
-            tap = tap < 9 ? tap : 8;
-            const int hy = (fr >> 3) + tap / 3, hx = (fr & 7) + tap % 3;
-            boff[ks] = ((hy * HW_ + hx) * 8 + ((gq * 2 + (fg & 1)) ^ (hx & 6))) * 16;
-        }
+        const int pt0 = ((wave % PW) >> 2) * (16 / PW);          // first pixel tile of this producer wave (MFMA stencil)
 #pragma unroll
         for (int it = 0; it < NBUF - 1; ++it)
             if (it < NTOT) issue(it);
@@ -225,44 +273,8 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
                 const float* Wl = reinterpret_cast<const float*>(Ring + (i % NBUF) * BUFB + NPG * HGB) + grp * KCW;
                 char* At = At0 + (i & 1) * AT_BYTES + grp * KCW * SZ;
                 if constexpr (MC != 0) {
-                    // ---- depthwise 3x3 on the MFMA: this wave = the 16-channel group gq of its 64-channel halo tile, all 4 pixel tiles ----
-                    constexpr int NKS = MC == 2 ? 9 : 5;
-                    const float* wc = Wl + gq * 16 + fr;                  // this lane's channel in the tap table [10][KC]
-                    Frag<T> af[NKS];
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) {
-                        unsigned v16;
-                        if constexpr (MC == 2) {                          // k-step = tap ks; lane groups 0,1: hi part, 2,3: lo part
-                            const float w = wc[ks * KC];
-                            const unsigned hi = cvt16<T>(w);
-                            v16 = (fg >> 1) ? cvt16<T>(w - back16<T>(hi)) : hi;
-                        } else {                                          // k-step = taps 2ks (lane groups 0,1) and 2ks+1 (2,3); tap 9 = padding
-                            const int tap = 2 * ks + (fg >> 1);
-                            const float w = wc[(tap < 9 ? tap : 8) * KC];
-                            v16 = tap < 9 ? cvt16<T>(w) : 0u;
-                        }
-                        const unsigned sh = v16 << hshift;
-                        af[ks].v = u32x4{sh & msk[0], sh & msk[1], sh & msk[2], sh & msk[3]};
-                    }
-                    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(Wl + 9 * KC + gq * 16 + fg * 4);
-                    f32x4 cacc[PTW];
-#pragma unroll
-                    for (int pt = 0; pt < PTW; ++pt) cacc[pt] = bias4;
-                    const char* Hp = Hs + pt0 * (2 * HW_ * PS);
-#pragma unroll
-                    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-                        for (int pt = 0; pt < PTW; ++pt) {
-                            Frag<T> bf;
-                            bf.v = *reinterpret_cast<const u32x4*>(Hp + boff[ks] + pt * (2 * HW_ * PS));
-                            mma16(cacc[pt], af[ks], bf);                  // weights as A: lane = pixel fr, channels 4 fg .. 4 fg + 3
-                        }
-                    }
-#pragma unroll
-                    for (int pt = 0; pt < PTW; ++pt) {
-                        gelu4<T>(cacc[pt]);
-                        store4(reinterpret_cast<T*>(At + ((pt0 + pt) * 16 + fr) * SAT) + gq * 16 + fg * 4, cacc[pt]);
-                    }
+                    // ---- depthwise 3x3 on the MFMA: this wave = the 16-channel group gq of its 64-channel halo tile, pixel tiles pt0 .. pt0 + PTW - 1 ----
+                    mconv_job<T, MC, PTW, KC, SAT, 2 * HW_ * PS>(Hs, Wl, At, gq, pt0, boff, msk, hshift, fr, fg);
                 } else {
                 float o[SR][8];
 #pragma unroll
@@ -345,7 +357,7 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
     // intervals, so their L2 round trip hides under the wait for the stencil.  After the last interval of a tile: epilogue
     // (+ bias + residual, in place on the f32 stream, model.py:987), accumulators back to zero.  Where the registers allow
     // (C <= 128) the residual rows of a tile are requested at the start of its last interval.
-    constexpr bool XPRE = SZ == 2 && TNW * TMW <= 4;        // C <= 64 (16 registers); at C = 128 the 32 registers spill under the 80-register bound
+    constexpr bool XPRE = SZ == 2 && TNW * TMW <= 4 && CP == 0;        // C <= 64 (16 registers); at C = 128 the 32 registers spill under the 80-register bound
     f32x4 xres[XPRE ? TNW : 1][XPRE ? TMW : 1];
     auto x_ptr = [&](int b, int y0, int x0, int i, int j) -> float* {
         const int n = (wn * TNW + i) * 16 + fg * 4;
@@ -407,6 +419,13 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
                 }
             }
         }
+        if constexpr (CP > 0) {
+            if (j < NTOT) {       // this wave's stencil job of interval j: group gq, pixel tile 4 - CP + cw / 4 (halo tile landed before the last barrier)
+                const char* Hs = Ring + (j % NBUF) * BUFB;
+                const float* Wl = reinterpret_cast<const float*>(Ring + (j % NBUF) * BUFB + NPG * HGB);
+                mconv_job<T, MC, 1, KC, SAT, 2 * HW_ * PS>(Hs, Wl, At0 + (j & 1) * AT_BYTES, gq, 4 - CP + (cw >> 2), boff, msk, hshift, fr, fg);
+            }
+        }
         ct1 = __builtin_readcyclecounter(); ctw += ct1 - ct0; ct0 = ct1;
         lds_barrier();
         ct1 = __builtin_readcyclecounter(); ctbar += ct1 - ct0; ct0 = ct1;
@@ -419,13 +438,13 @@ __global__ __launch_bounds__((PW * NPG + NC) * 64, WPS) void leff2_kernel(const 
     }
 }
 
-template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4>
+template <typename T, int C, int NPG, int NC, int NBUF, int WPS, int PW = 4, int CP = 0>
 int launch_v(const Leff2Params& p, hipStream_t st) {
     constexpr int SZ = sizeof(T), KC = KCW * NPG;
     constexpr int HGB = (100 * KCW * SZ + 1023) / 1024 * 1024, TGB = (10 * KC * 4 + 1023) / 1024 * 1024;
     constexpr int smem = NBUF * (NPG * HGB + TGB) + 2 * 64 * (KC * SZ + 16) + 1024;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = leff2_kernel<T, C, NPG, NC, NBUF, WPS, PW>;
+    auto kern = leff2_kernel<T, C, NPG, NC, NBUF, WPS, PW, CP>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "leff2")) return rc;
     const long long M = (long long)p.B * p.H * p.W;
@@ -473,6 +492,13 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
         // workgroups cost residency (dec1 0.631 -> 0.739, C <= 64 +4...9 %): profiles/r04_run2.txt.  UF_LEFF2_VARIANT=p forces it, =n never.
         static const char* ev = getenv("UF_LEFF2_VARIANT");
         const bool force = ev && ev[0] == 'p', never = ev && ev[0] == 'n';
+        // UF_LEFF2_VARIANT=c: consumer waves take a quarter (C <= 256) / half (C = 512) of the stencil jobs (template parameter CP)
+        const bool cj = ev ? ev[0] == 'c' : UF_LEFF2_CP_DEFAULT;
+        if (cj) {
+            if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6, 4, 1>(p, st);
+            else if constexpr (C == 256) return launch_v<T, C, 1, 4, 3, 4, 4, 1>(p, st);
+            else return launch_v<T, C, 1, 8, 3, 3, 4, 2>(p, st);
+        }
         if constexpr (C == 128) { if (!never && (force || tiles <= 1024)) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
         else if constexpr (C == 256) { if (!never && (force || tiles <= 256)) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st); }
         else if constexpr (C == 512) { if (force) return launch_v<T, C, 1, 8, 4, 4, 8>(p, st); }
