@@ -834,8 +834,11 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
 
     // low-register form at C <= 128 (see attn_block_kernel): UF_ATTN_LR=1 with the tighter register bound (one more workgroup per CU),
     // =2 the same code at the occupancy of the first form, =0 the first form (A/B runs)
+    // Default by shape, from the same-box A/B of the three bit-identical forms (profiles/r04_run4.txt, ms per step: first / LR=1 / LR=2):
+    // C = 32 (enc0) 0.187 / 0.212 / 0.172 -> LR=2; C = 128 with >= 4096 windows (dec2) 0.409 / 0.383 / 0.406 -> LR=1; everything else stays
+    // on the first form (C = 128 with 1024 windows 0.445 / 0.445 / 0.467, C = 64 0.361 / 0.373 / 0.366 and 0.177 / 0.179 / 0.183).
     static const char* elr = getenv("UF_ATTN_LR");
-    const int lr = elr ? atoi(elr) : UF_ATTN_LR_DEFAULT;
+    const int lr = elr ? atoi(elr) : (C == 32 ? 2 : ((C == 128 && p.n_windows >= 4096) ? 1 : 0));
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
 #define UF_AB_HALF(TT)                                                                                                              \
         switch (C) {                                                                                                                    \
