@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4, GPU call 8: window_attn_bwd2 (chained accumulators): backward test suite, micro-benchmark and training step against the first version
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out; mkdir -p $O; cd $R
+tb() { python scripts/train_bench.py --batch 32 --steps 3 --warmup 2 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(round(d['value'],1), 'img/s', round(d.get('ms_per_step',0),2), 'ms')"; }
+{
+echo "== pytest test_gpu_bwd + tail"; python -m pytest tests/test_gpu_bwd.py tests/test_gpu_tail.py -m gpu -q 2>&1 | tail -6
+echo "== attn bwd microbench, first version"; UF_ATTN_BWD_V1=1 python scripts/ubench_train.py attn 2>/dev/null
+echo "== attn bwd microbench, second version"; python scripts/ubench_train.py attn 2>/dev/null
+for r in 1 2; do echo "train attn_bwd v1 run $r: $(UF_ATTN_BWD_V1=1 tb)"; echo "train attn_bwd v2 run $r: $(tb)"; done
+echo "train f16 (dynamic scaler in bench only; train_bench static): $(tb --dtype f16)"
+} 2>&1 | grep -v amdgpu.ids | tee $O/r04_run8.txt

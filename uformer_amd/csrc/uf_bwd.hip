@@ -1229,6 +1229,253 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
         for (int r = 0; r < 4; ++r) wb[(i0 + 4 * fg + r) * 64 + 16 * t + fr] = adb[t][r];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Window attention backward, second version (round 4; 2-byte operand types): the accumulators of S / dP are chained straight into the
+// operands of the three output products, as the forward kernel does -- P and dS never touch LDS, nothing is stored transposed.
+//
+// A chained accumulator D[row][col] can only be the B operand of a product that contracts over its ROWS with output column = its column
+// (FragFromAcc).  dq contracts over keys, dk and dv over queries, so every wave evaluates BOTH orientations of the 64 x 64 tiles:
+//   phase A (wave w = query tile w):  S^T[k][q] = K Q^T,  dP^T[k][q] = V dO^T  -> softmax statistics per query (in-lane + xor 16 / 32),
+//            dS^T -> dbias slice, row statistics (max, 1 / sum, dot) to LDS, and dq^T[d][q] = sum_k K^T[d][k] dS^T[k][q]  (dS chained);
+//   phase B (wave w = key tile w):    S[q][k] = Q K^T,  dP[q][k] = dO V^T with the statistics of phase A -> P, dS, then
+//            dk^T[d][k] = sum_q Q^T[d][q] dS[q][k]  and  dv^T[d][k] = sum_q dO^T[d][q] P[q][k]                      (dS, P chained).
+// The 2 x 16 extra MFMAs per window are free next to what they replace: the first version wrote q, k, dO transposed and P, dS in both
+// orientations into LDS with 2-byte scalar stores (~24 K per window and head) and ran at ~100 TFLOP/s (profiles/r03_train_final_kernel_stats.csv:
+// 6.6 ms of a 79 ms training step).  LDS holds only the four operand tiles as they sit in HBM (q, k, dO token-major [64][32], v^T [32][64],
+// 16-byte staging stores); an operand that is needed transposed (K^T, Q^T, dO^T as A operands with 8 tokens per lane; V from v^T) comes
+// out of LDS through gfx950's transposing read ds_read_b64_tr_b16 (mapping: linear_wgrad2 above).  Two barriers per window.
+// Same products, the same softmax algebra; the order of the 32-deep / 64-deep sums inside an MFMA chain is the hardware's in both versions:
+// results agree with the first version to operand rounding (tests/test_gpu_bwd.py compares both with the oracle).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32x4 tr_frag(unsigned a0, unsigned a1) {     // 8 contraction slots of one column: rows a0 .. +3 and a1 .. +3 of the lane group
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
+                                                               const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
+                                                               const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
+                                                               T* __restrict__ dvt, T* __restrict__ dqkv, float qscale, float* __restrict__ ws_bias, int n_windows,
+                                                               int heads, int H, int W, int shift) {
+    static_assert(sizeof(T) == 2 && (HD == 16 || HD == 32), "2-byte operand types, head_dim 16 or 32");
+    constexpr int NDT = HD / 16;
+    constexpr int SD = 32 * 2 + 16, ST = 64 * 2 + 16;            // row strides: [token][32 d slots] tiles, v^T [32 d][64 tokens]
+    __shared__ __attribute__((aligned(16))) char Qs[64 * SD];
+    __shared__ __attribute__((aligned(16))) char Ks[64 * SD];
+    __shared__ __attribute__((aligned(16))) char Gs[64 * SD];
+    __shared__ __attribute__((aligned(16))) char Vt[32 * ST];
+    __shared__ __attribute__((aligned(16))) float Stat[3][64];     // per query row: max, 1 / sum, sum_k P dP
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.x;
+    const int w0 = (int)((long long)n_windows * blockIdx.y / gridDim.y), w1 = (int)((long long)n_windows * (blockIdx.y + 1) / gridDim.y);
+    const int i0 = wave * 16;                                      // this wave's query tile (phase A) and key tile (phase B)
+    const int nWc = W >> 3, nW = (H >> 3) * nWc;
+    const unsigned qb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs, kb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ks;
+    const unsigned gb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Gs, vb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Vt;
+
+    // relative-position bias of the elements this lane owns, cached for all windows of the chunk.  Phase A: query i0 + fr, keys 16 t + 4 fg + r;
+    // phase B: queries 16 t + 4 fg + r, key i0 + fr.
+    f32x4 brA[4], brB[4], adb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        adb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        brA[t] = *reinterpret_cast<const f32x4*>(bias_dense + (size_t)h * 4096 + (i0 + fr) * 64 + 16 * t + 4 * fg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) brB[t][r] = bias_dense[(size_t)h * 4096 + (16 * t + 4 * fg + r) * 64 + i0 + fr];
+    }
+    if constexpr (HD == 16) {        // the zero halves of the 32-slot tiles (never written again): d slots 16..31 of q, k, dO and rows 16..31 of v^T
+        for (int e = tid; e < 3 * 64 * 2; e += 256) {
+            const int tile = e / 128, row = (e >> 1) & 63, pc = 2 + (e & 1);
+            char* base = tile == 0 ? Qs : (tile == 1 ? Ks : Gs);
+            *reinterpret_cast<u32x4*>(base + row * SD + pc * 16) = u32x4{0, 0, 0, 0};
+        }
+        for (int e = tid; e < 16 * 8; e += 256) *reinterpret_cast<u32x4*>(Vt + (16 + (e >> 3)) * ST + (e & 7) * 16) = u32x4{0, 0, 0, 0};
+    }
+    // tr-read addresses (tile-relative): an A operand "rows = 16 channels d of tile c, 8 contraction slots = tokens" out of a token-major tile:
+    // lane (fg, fr) addresses token row (base + fr / 4) and the 4 channels 16 c + 4 (fr % 4) .. of it.  For operands that meet a CHAINED accumulator the
+    // lane group's 8 slots are tokens 32 sk + 4 fg + {0..3} and 32 sk + 16 + 4 fg + {0..3} (FragFromAcc order).
+    auto tr_tok = [&](unsigned base, int sk, int c) -> u32x4 {
+        const unsigned a0 = base + (unsigned)((32 * sk + 4 * fg + (fr >> 2)) * SD + (16 * c + 4 * (fr & 3)) * 2);
+        return tr_frag(a0, a0 + 16 * SD);
+    };
+#pragma unroll 1
+    for (int bw = w0; bw < w1; ++bw) {
+        const size_t base = ((size_t)bw * heads + h) * (64 * HD);
+        // ---- stage q, k, dO (token-major) and v^T as they sit in HBM: one 16-byte piece per thread and tile (HD = 16: half the threads)
+        {
+            constexpr int PPR = HD / 8;                                   // 16-byte pieces per token row
+            if (tid < 64 * PPR) {
+                const int i = tid / PPR, pp = tid % PPR;
+                *reinterpret_cast<u32x4*>(Qs + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(q + base + i * HD + pp * 8);
+                *reinterpret_cast<u32x4*>(Ks + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(k + base + i * HD + pp * 8);
+                *reinterpret_cast<u32x4*>(Gs + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(dO + ((size_t)bw * 64 + i) * ldo + h * HD + pp * 8);
+            }
+            if (tid < HD * 8) {
+                const int d = tid >> 3, pp = tid & 7;
+                *reinterpret_cast<u32x4*>(Vt + d * ST + pp * 16) = *reinterpret_cast<const u32x4*>(vt + base + d * 64 + pp * 8);
+            }
+        }
+        __syncthreads();
+        const int wi = bw % nW;
+        const bool last_r = shift > 0 && (wi / nWc) == (H >> 3) - 1;
+        const bool last_c = shift > 0 && (wi % nWc) == nWc - 1;
+        const float* mk = mask ? mask + (size_t)(bw % n_mask) * 4096 : nullptr;
+
+        // ================= phase A: query tile i0 .. i0 + 15 in the columns =================
+        {
+            Frag<T> qf, gf;                                               // B operands: column = query i0 + fr, slots d = 8 fg ..
+            load_frag(qf, reinterpret_cast<const T*>(Qs + (i0 + fr) * SD) + fg * 8);
+            load_frag(gf, reinterpret_cast<const T*>(Gs + (i0 + fr) * SD) + fg * 8);
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Frag<T> kf, vf;                                           // A operands: row = key 16 t + fr, slots d
+                load_frag(kf, reinterpret_cast<const T*>(Ks + (16 * t + fr) * SD) + fg * 8);
+                const unsigned va = vb + (unsigned)((8 * fg + (fr >> 2)) * ST + (16 * t + 4 * (fr & 3)) * 2);     // V[k][d] out of v^T[d][k]
+                vf.v = tr_frag(va, va + 4 * ST);
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = s[t];
+                mma16(s[t], kf, qf);                                      // D[row = key 16 t + 4 fg + r][col = query i0 + fr]
+                mma16(dp[t], vf, gf);
+            }
+            const int qi = i0 + fr;
+            const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kj = 16 * t + 4 * fg + r;
+                    float v = s[t][r] + brA[t][r];
+                    if (mk) v += mk[qi * 64 + kj];
+                    const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;       // SW-MSA mask, model.py:924-942
+                    if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+            mx = red_xor32<RedMax>(red_xor16<RedMax>(mx));               // the four lane groups hold the other keys of this query
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][r] = __expf(s[t][r] - mx); sum += s[t][r]; }
+            const float inv = 1.0f / red_xor32<RedSum>(red_xor16<RedSum>(sum));
+            float dot = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][r] *= inv; dot += s[t][r] * dp[t][r]; }
+            dot = red_xor32<RedSum>(red_xor16<RedSum>(dot));
+            if (fg == 0) { Stat[0][qi] = mx; Stat[1][qi] = inv; Stat[2][qi] = dot; }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][r] = s[t][r] * (dp[t][r] - dot); adb[t][r] += s[t][r]; }      // s = dS^T now
+            // dq^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
+            f32x4 oq[NDT];
+#pragma unroll
+            for (int c = 0; c < NDT; ++c) oq[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                Frag<T> ds;
+                ds.v = u32x4{pack2<T>(s[2 * sk][0], s[2 * sk][1]), pack2<T>(s[2 * sk][2], s[2 * sk][3]), pack2<T>(s[2 * sk + 1][0], s[2 * sk + 1][1]), pack2<T>(s[2 * sk + 1][2], s[2 * sk + 1][3])};
+#pragma unroll
+                for (int c = 0; c < NDT; ++c) {
+                    Frag<T> kt_;
+                    kt_.v = tr_tok(kb, sk, c);
+                    mma16(oq[c], kt_, ds);                                // D[row d = 16 c + 4 fg + r][col q = i0 + fr]
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NDT; ++c) {
+                if (dqkv) {      // merged form: dq (times the query scale) in the first third of the row of token i0 + fr
+                    T* dst = dqkv + ((size_t)bw * 64 + qi) * (3 * heads * HD) + h * HD + 16 * c + 4 * fg;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(oq[c][0] * qscale, oq[c][1] * qscale), pack2<T>(oq[c][2] * qscale, oq[c][3] * qscale)};
+                } else {
+                    T* dst = dq + base + qi * HD + 16 * c + 4 * fg;
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{pack2<T>(oq[c][0], oq[c][1]), pack2<T>(oq[c][2], oq[c][3])};
+                }
+            }
+        }
+        __syncthreads();                                                  // the row statistics of all four query tiles
+        // ================= phase B: key tile i0 .. i0 + 15 in the columns =================
+        {
+            Frag<T> kf, vf;                                               // B operands: column = key i0 + fr, slots d
+            load_frag(kf, reinterpret_cast<const T*>(Ks + (i0 + fr) * SD) + fg * 8);
+            const unsigned va = vb + (unsigned)((8 * fg + (fr >> 2)) * ST + (i0 + 4 * (fr & 3)) * 2);
+            vf.v = tr_frag(va, va + 4 * ST);
+            f32x4 s[4], dp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Frag<T> qf, gf;                                           // A operands: row = query 16 t + fr, slots d
+                load_frag(qf, reinterpret_cast<const T*>(Qs + (16 * t + fr) * SD) + fg * 8);
+                load_frag(gf, reinterpret_cast<const T*>(Gs + (16 * t + fr) * SD) + fg * 8);
+                s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = s[t];
+                mma16(s[t], qf, kf);                                      // D[row = query 16 t + 4 fg + r][col = key i0 + fr]
+                mma16(dp[t], gf, vf);
+            }
+            const int kj = i0 + fr;
+            const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;
+            f32x4 pr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const f32x4 mxs = *reinterpret_cast<const f32x4*>(&Stat[0][16 * t + 4 * fg]), ivs = *reinterpret_cast<const f32x4*>(&Stat[1][16 * t + 4 * fg]);
+                const f32x4 dts = *reinterpret_cast<const f32x4*>(&Stat[2][16 * t + 4 * fg]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = 16 * t + 4 * fg + r;
+                    float v = s[t][r] + brB[t][r];
+                    if (mk) v += mk[qi * 64 + kj];
+                    const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+                    if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    const float pv = __expf(v - mxs[r]) * ivs[r];
+                    pr[t][r] = pv;
+                    s[t][r] = pv * (dp[t][r] - dts[r]);                   // dS
+                }
+            }
+            f32x4 ok[NDT], ov[NDT];
+#pragma unroll
+            for (int c = 0; c < NDT; ++c) { ok[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ov[c] = ok[c]; }
+#pragma unroll
+            for (int sk = 0; sk < 2; ++sk) {
+                Frag<T> ds, pf;
+                ds.v = u32x4{pack2<T>(s[2 * sk][0], s[2 * sk][1]), pack2<T>(s[2 * sk][2], s[2 * sk][3]), pack2<T>(s[2 * sk + 1][0], s[2 * sk + 1][1]), pack2<T>(s[2 * sk + 1][2], s[2 * sk + 1][3])};
+                pf.v = u32x4{pack2<T>(pr[2 * sk][0], pr[2 * sk][1]), pack2<T>(pr[2 * sk][2], pr[2 * sk][3]), pack2<T>(pr[2 * sk + 1][0], pr[2 * sk + 1][1]), pack2<T>(pr[2 * sk + 1][2], pr[2 * sk + 1][3])};
+#pragma unroll
+                for (int c = 0; c < NDT; ++c) {
+                    Frag<T> qt_, gt_;
+                    qt_.v = tr_tok(qb, sk, c);
+                    gt_.v = tr_tok(gb, sk, c);
+                    mma16(ok[c], qt_, ds);                                // dk^T: D[row d][col key i0 + fr]
+                    mma16(ov[c], gt_, pf);                                // dv^T
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NDT; ++c) {
+                const u32x2 pk = u32x2{pack2<T>(ok[c][0], ok[c][1]), pack2<T>(ok[c][2], ok[c][3])}, pv = u32x2{pack2<T>(ov[c][0], ov[c][1]), pack2<T>(ov[c][2], ov[c][3])};
+                if (dqkv) {
+                    T* row = dqkv + ((size_t)bw * 64 + kj) * (3 * heads * HD) + h * HD + 16 * c + 4 * fg;
+                    *reinterpret_cast<u32x2*>(row + heads * HD) = pk;
+                    *reinterpret_cast<u32x2*>(row + 2 * heads * HD) = pv;
+                } else {
+                    *reinterpret_cast<u32x2*>(dk + base + kj * HD + 16 * c + 4 * fg) = pk;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) store1(dvt + base + (16 * c + 4 * fg + r) * 64 + kj, ov[c][r]);
+                }
+            }
+        }
+        __syncthreads();   // the next window overwrites the tiles
+    }
+    float* wb = ws_bias + ((size_t)blockIdx.y * heads + h) * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(wb + (i0 + fr) * 64 + 16 * t + 4 * fg) = adb[t];
+}
+
 }  // namespace
 }  // namespace uf
 
@@ -1530,7 +1777,17 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
                                bias_dense, mask, n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows,    \
                                heads, H, W, shift);                                                                                                   \
         }
+        // second version (accumulators chained into the operands, nothing stored transposed) for the 2-byte types; UF_ATTN_BWD_V1=1: first version
+        const char* ev1 = getenv("UF_ATTN_BWD_V1");
+        const bool v2 = dtype_half(dtype) && !(ev1 && ev1[0] == '1') && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)dO % 16) == 0;
+#define UF_ATTN_BWD2(TT, HDV)                                                                                                                       \
+        hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
+                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
+        if (v2 && dtype == UF_BF16) { if (head_dim == 32) { UF_ATTN_BWD2(bf16, 32) } else { UF_ATTN_BWD2(bf16, 16) } }
+        else if (v2) { if (head_dim == 32) { UF_ATTN_BWD2(f16, 32) } else { UF_ATTN_BWD2(f16, 16) } }
+        else
         UF_DISPATCH(dtype, TT, { if (head_dim == 32) UF_ATTN_BWD(TT, 32) else UF_ATTN_BWD(TT, 16) });
+#undef UF_ATTN_BWD2
 #undef UF_ATTN_BWD
     }
     int rc = check_launch("window_attn_bwd");
