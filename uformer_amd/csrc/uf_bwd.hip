@@ -1248,14 +1248,17 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 // Same products, the same softmax algebra; the order of the 32-deep / 64-deep sums inside an MFMA chain is the hardware's in both versions:
 // results agree with the first version to operand rounding (tests/test_gpu_bwd.py compares both with the oracle).
 // ---------------------------------------------------------------------------------------------------------------
+#ifndef UF_ATTN_BWD2_WPS
+#define UF_ATTN_BWD2_WPS 3      // waves per SIMD the no-mask instantiation is bounded for (3: 168 registers, 11 spilled dwords; 2: no spill)
+#endif
 __device__ __forceinline__ u32x4 tr_frag(unsigned a0, unsigned a1) {     // 8 contraction slots of one column: rows a0 .. +3 and a1 .. +3 of the lane group
     u32x2 lo, hi;
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1) : "memory");
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
+template <typename T, int HD, bool MK>
+__global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bwd2_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ vt,
                                                                const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
                                                                const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
                                                                T* __restrict__ dvt, T* __restrict__ dqkv, float qscale, float* __restrict__ ws_bias, int n_windows,
@@ -1268,6 +1271,7 @@ __global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __res
     __shared__ __attribute__((aligned(16))) char Gs[64 * SD];
     __shared__ __attribute__((aligned(16))) char Vt[32 * ST];
     __shared__ __attribute__((aligned(16))) float Stat[3][64];     // per query row: max, 1 / sum, sum_k P dP
+    __shared__ __attribute__((aligned(16))) float Bs[64][68];       // this head's relative-position bias [query][key], rows padded to 272 bytes (conflict-free 16-byte reads)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -1278,16 +1282,12 @@ __global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __res
     const unsigned qb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs, kb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ks;
     const unsigned gb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Gs, vb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Vt;
 
-    // relative-position bias of the elements this lane owns, cached for all windows of the chunk.  Phase A: query i0 + fr, keys 16 t + 4 fg + r;
-    // phase B: queries 16 t + 4 fg + r, key i0 + fr.
-    f32x4 brA[4], brB[4], adb[4];
+    // relative-position bias of this head: staged once in LDS (it cost 32 registers per lane as two per-lane caches: the kernel spilled at three waves
+    // per SIMD); phase A reads 4 consecutive keys of query i0 + fr, phase B the key i0 + fr of 4 consecutive queries
+    for (int e = tid; e < 64 * 16; e += 256) *reinterpret_cast<f32x4*>(&Bs[e >> 4][(e & 15) * 4]) = *reinterpret_cast<const f32x4*>(bias_dense + (size_t)h * 4096 + e * 4);
+    f32x4 adb[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        adb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        brA[t] = *reinterpret_cast<const f32x4*>(bias_dense + (size_t)h * 4096 + (i0 + fr) * 64 + 16 * t + 4 * fg);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) brB[t][r] = bias_dense[(size_t)h * 4096 + (16 * t + 4 * fg + r) * 64 + i0 + fr];
-    }
+    for (int t = 0; t < 4; ++t) adb[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if constexpr (HD == 16) {        // the zero halves of the 32-slot tiles (never written again): d slots 16..31 of q, k, dO and rows 16..31 of v^T
         for (int e = tid; e < 3 * 64 * 2; e += 256) {
             const int tile = e / 128, row = (e >> 1) & 63, pc = 2 + (e & 1);
@@ -1303,28 +1303,38 @@ __global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __res
         const unsigned a0 = base + (unsigned)((32 * sk + 4 * fg + (fr >> 2)) * SD + (16 * c + 4 * (fr & 3)) * 2);
         return tr_frag(a0, a0 + 16 * SD);
     };
+    // the four operand pieces of a window travel HBM -> registers one window AHEAD (requested right after the staging barrier, stored to LDS at the top of
+    // the next iteration): the global round trip hides under the previous window's products instead of standing in front of every window
+    constexpr int PPR = HD / 8;                                           // 16-byte pieces per token row
+    const bool ld_tok = tid < 64 * PPR, ld_vt = tid < HD * 8;
+    const int ti = tid / PPR, tp = tid % PPR, vd = tid >> 3, vp = tid & 7;
+    u32x4 rq = {0, 0, 0, 0}, rk = rq, rg = rq, rv = rq;
+    auto fetch = [&](int bw) {
+        const size_t base = ((size_t)bw * heads + h) * (64 * HD);
+        if (ld_tok) {
+            rq = *reinterpret_cast<const u32x4*>(q + base + ti * HD + tp * 8);
+            rk = *reinterpret_cast<const u32x4*>(k + base + ti * HD + tp * 8);
+            rg = *reinterpret_cast<const u32x4*>(dO + ((size_t)bw * 64 + ti) * ldo + h * HD + tp * 8);
+        }
+        if (ld_vt) rv = *reinterpret_cast<const u32x4*>(vt + base + vd * 64 + vp * 8);
+    };
+    if (w0 < w1) fetch(w0);
 #pragma unroll 1
     for (int bw = w0; bw < w1; ++bw) {
         const size_t base = ((size_t)bw * heads + h) * (64 * HD);
         // ---- stage q, k, dO (token-major) and v^T as they sit in HBM: one 16-byte piece per thread and tile (HD = 16: half the threads)
-        {
-            constexpr int PPR = HD / 8;                                   // 16-byte pieces per token row
-            if (tid < 64 * PPR) {
-                const int i = tid / PPR, pp = tid % PPR;
-                *reinterpret_cast<u32x4*>(Qs + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(q + base + i * HD + pp * 8);
-                *reinterpret_cast<u32x4*>(Ks + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(k + base + i * HD + pp * 8);
-                *reinterpret_cast<u32x4*>(Gs + i * SD + pp * 16) = *reinterpret_cast<const u32x4*>(dO + ((size_t)bw * 64 + i) * ldo + h * HD + pp * 8);
-            }
-            if (tid < HD * 8) {
-                const int d = tid >> 3, pp = tid & 7;
-                *reinterpret_cast<u32x4*>(Vt + d * ST + pp * 16) = *reinterpret_cast<const u32x4*>(vt + base + d * 64 + pp * 8);
-            }
+        if (ld_tok) {
+            *reinterpret_cast<u32x4*>(Qs + ti * SD + tp * 16) = rq;
+            *reinterpret_cast<u32x4*>(Ks + ti * SD + tp * 16) = rk;
+            *reinterpret_cast<u32x4*>(Gs + ti * SD + tp * 16) = rg;
         }
+        if (ld_vt) *reinterpret_cast<u32x4*>(Vt + vd * ST + vp * 16) = rv;
         __syncthreads();
+        if (bw + 1 < w1) fetch(bw + 1);
         const int wi = bw % nW;
         const bool last_r = shift > 0 && (wi / nWc) == (H >> 3) - 1;
         const bool last_c = shift > 0 && (wi % nWc) == nWc - 1;
-        const float* mk = mask ? mask + (size_t)(bw % n_mask) * 4096 : nullptr;
+        const float* mk = MK ? mask + (size_t)(bw % n_mask) * 4096 : nullptr;      // dense caller-supplied mask (inference-only argument of the reference): own instantiation
 
         // ================= phase A: query tile i0 .. i0 + 15 in the columns =================
         {
@@ -1347,11 +1357,12 @@ __global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __res
             float mx = -3.0e38f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                const f32x4 brA = *reinterpret_cast<const f32x4*>(&Bs[qi][16 * t + 4 * fg]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kj = 16 * t + 4 * fg + r;
-                    float v = s[t][r] + brA[t][r];
-                    if (mk) v += mk[qi * 64 + kj];
+                    float v = s[t][r] + brA[r];
+                    if constexpr (MK) v += mk[qi * 64 + kj];
                     const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;       // SW-MSA mask, model.py:924-942
                     if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
                     s[t][r] = v;
@@ -1429,8 +1440,8 @@ __global__ __launch_bounds__(256, 2) void window_attn_bwd2_kernel(const T* __res
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int qi = 16 * t + 4 * fg + r;
-                    float v = s[t][r] + brB[t][r];
-                    if (mk) v += mk[qi * 64 + kj];
+                    float v = s[t][r] + Bs[qi][kj];
+                    if constexpr (MK) v += mk[qi * 64 + kj];
                     const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
                     if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
                     const float pv = __expf(v - mxs[r]) * ivs[r];
@@ -1781,7 +1792,9 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
         const char* ev1 = getenv("UF_ATTN_BWD_V1");
         const bool v2 = dtype_half(dtype) && !(ev1 && ev1[0] == '1') && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)dO % 16) == 0;
 #define UF_ATTN_BWD2(TT, HDV)                                                                                                                       \
-        hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
+        if (mask) hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV, true>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
+                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);                            \
+        else hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV, false>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
                            n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
         if (v2 && dtype == UF_BF16) { if (head_dim == 32) { UF_ATTN_BWD2(bf16, 32) } else { UF_ATTN_BWD2(bf16, 16) } }
         else if (v2) { if (head_dim == 32) { UF_ATTN_BWD2(f16, 32) } else { UF_ATTN_BWD2(f16, 16) } }
