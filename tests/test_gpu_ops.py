@@ -362,6 +362,49 @@ def test_lewin_block_golden(golden, dtype, tag):
             check(f"lewin_block_{tag}_shift{shift}_usermask", blk(x[:1], um, dtype), t(g[f"y_shift{shift}_usermask"]), dtype)
 
 
+def test_leff2_and_attn_block_variants_bit_identical():
+    """The launch variants that are chosen by shape (and therefore by batch size) must agree bit for bit, or a batch-16 forward would not equal 16
+    single forwards: leff2 with 8 producer waves / consumer stencil jobs / the persistent tile walk, attn_block in its low-register forms.  The
+    switches are read once per process, so every variant runs in a child process and returns hashes of its outputs on the same inputs."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from uformer_amd import model as um, ops
+out = []
+for (B, H, C) in ((1, 64, 128), (5, 64, 128), (1, 32, 256), (9, 32, 256), (1, 32, 512), (3, 64, 64), (2, 128, 32)):
+    g = torch.Generator().manual_seed(B * 7 + H + C)
+    h1 = torch.randn(B, H, H, 4 * C, generator=g).to(torch.bfloat16).cuda()
+    w9 = (torch.randn(9, 4 * C, generator=g) * 0.2).cuda(); bd = (torch.randn(4 * C, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5).to(torch.bfloat16).cuda(); b2 = torch.randn(C, generator=g).cuda()
+    x = torch.randn(B * H * H, C, generator=g).cuda()
+    y = ops.dwconv_linear2(h1, w9, bd, w2, b2, x)
+    out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16])
+for (B, H, C, heads) in ((2, 64, 32, 1), (1, 128, 128, 4), (2, 32, 64, 2)):
+    torch.manual_seed(C + H)
+    blk = um.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
+    xb = torch.randn(B, H * H, C, generator=torch.Generator().manual_seed(3)).cuda()
+    with torch.no_grad():
+        y = blk(xb, None, torch.bfloat16)
+    out.append(hashlib.sha256(y.float().cpu().numpy().tobytes()).hexdigest()[:16])
+print("HASHES " + " ".join(out))
+""" % root
+    res = {}
+    for tag, env in (("default", {}), ("leff2 8 producers", {"UF_LEFF2_VARIANT": "p"}), ("leff2 never 8 producers", {"UF_LEFF2_VARIANT": "n"}),
+                     ("leff2 consumer stencil jobs", {"UF_LEFF2_VARIANT": "c"}), ("leff2 one tile per workgroup", {"UF_LEFF2_PERSIST": "0"}),
+                     ("leff2 tile walk everywhere", {"UF_LEFF2_PERSIST": "1"}), ("attn_block first form", {"UF_ATTN_LR": "0"}),
+                     ("attn_block low-register form", {"UF_ATTN_LR": "1"}), ("attn_block low-register code, first bounds", {"UF_ATTN_LR": "2"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASHES ")]
+        assert r.returncode == 0 and line, (tag, r.stdout[-1500:], r.stderr[-1500:])
+        res[tag] = line[0]
+    for tag, v in res.items():
+        assert v == res["default"], f"{tag}: outputs differ from the default variant\n{v}\n{res['default']}"
+
+
 @pytest.mark.parametrize("dtype", MODES)
 def test_samplers_golden(golden, dtype):
     from uformer_amd import model

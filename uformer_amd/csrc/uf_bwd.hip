@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(const T* __restric
 // results agree with the first version to operand rounding (tests/test_gpu_bwd.py compares both with the oracle).
 // ---------------------------------------------------------------------------------------------------------------
 #ifndef UF_ATTN_BWD2_WPS
-#define UF_ATTN_BWD2_WPS 3      // waves per SIMD the no-mask instantiation is bounded for (3: 168 registers, 11 spilled dwords; 2: no spill)
+#define UF_ATTN_BWD2_WPS 2      // waves per SIMD the kernel is bounded for: 3 (168 registers) spills 11 dwords and measured 2374 us over the nine stage shapes against 1777 at 2 (profiles/r04_run9.txt)
 #endif
 __device__ __forceinline__ u32x4 tr_frag(unsigned a0, unsigned a1) {     // 8 contraction slots of one column: rows a0 .. +3 and a1 .. +3 of the lane group
     u32x2 lo, hi;
@@ -1334,6 +1334,7 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
         const int wi = bw % nW;
         const bool last_r = shift > 0 && (wi / nWc) == (H >> 3) - 1;
         const bool last_c = shift > 0 && (wi % nWc) == nWc - 1;
+        const bool edge = last_r || last_c;
         const float* mk = MK ? mask + (size_t)(bw % n_mask) * 4096 : nullptr;      // dense caller-supplied mask (inference-only argument of the reference): own instantiation
 
         // ================= phase A: query tile i0 .. i0 + 15 in the columns =================
@@ -1363,8 +1364,10 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
                     const int kj = 16 * t + 4 * fg + r;
                     float v = s[t][r] + brA[r];
                     if constexpr (MK) v += mk[qi * 64 + kj];
-                    const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;       // SW-MSA mask, model.py:924-942
-                    if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    if (edge) {                                                       // SW-MSA mask, model.py:924-942: only the windows of the last row / column have one (wave-uniform)
+                        const bool k_lo_y = (kj >> 3) >= 4, k_lo_x = (kj & 7) >= 4;
+                        if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    }
                     s[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -1442,8 +1445,10 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
                     const int qi = 16 * t + 4 * fg + r;
                     float v = s[t][r] + Bs[qi][kj];
                     if constexpr (MK) v += mk[qi * 64 + kj];
-                    const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
-                    if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    if (edge) {
+                        const bool q_lo_y = (qi >> 3) >= 4, q_lo_x = (qi & 7) >= 4;
+                        if ((last_r && (k_lo_y != q_lo_y)) || (last_c && (k_lo_x != q_lo_x))) v += -100.0f;
+                    }
                     const float pv = __expf(v - mxs[r]) * ivs[r];
                     pr[t][r] = pv;
                     s[t][r] = pv * (dp[t][r] - dts[r]);                   // dS
