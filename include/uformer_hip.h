@@ -250,6 +250,15 @@ int uf_layernorm_bwd(const float* x, int ld_x, const float* gamma, const float* 
 int uf_layernorm_bwd_fused(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32,
                            const float* add, float* dx, int ld_dx, float* dgamma, float* dbeta, int B, int H, int W, int C,
                            int windowed, int shift, uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* uf_layernorm_bwd_fused with a second output: cast_out T[B*H*W][C] = T(dx * cast_scale[image]) (cast_scale f32[B] or NULL) written at the
+ * token's own row, or at its window-order row when cast_windowed (roll by -cast_shift + window_partition, model.py:957-963) -- the GEMM
+ * operand the next step of the backward reads (the block's attention branch after LN2's backward, the preceding block's LeFF branch after
+ * LN1's), which uf_grad_fork otherwise makes in a pass of its own.  dy of the operand type (dy_is_f32 = 0, or dtype f32).  dx, dgamma,
+ * dbeta are bit-identical to uf_layernorm_bwd_fused; cast_out is bit-identical to uf_grad_fork of the dx this call wrote.  Same workspace. */
+int uf_layernorm_bwd_cast(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32,
+                          const float* add, float* dx, int ld_dx, float* dgamma, float* dbeta, int B, int H, int W, int C,
+                          int windowed, int shift, uf_dtype dtype, void* cast_out, const float* cast_scale, int cast_windowed, int cast_shift,
+                          void* ws, size_t ws_bytes, void* stream);
 /* nn.Linear weight / bias gradients: dW f32[N][K] = sum_m dY[m][n] X[m][k], db f32[N] = sum_m dY[m][n] (db may be NULL),
  * OVERWRITTEN.  dY T[M][ldy] (N columns), X T[M][ldx] (K columns); N, K, ldy, ldx multiples of 16 bytes / sizeof(T).
  * (The input gradient dX = dY W is uf_linear_fwd with the transposed weight.) */

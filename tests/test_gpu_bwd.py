@@ -146,10 +146,12 @@ torch.save((da.cpu(), dw.cpu(), db.cpu()), sys.argv[2])
 
 
 @pytest.mark.parametrize("dtype", MODES)
-@pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512)])
-def test_linear_wgrad_and_input_grad(dtype, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512),
+                                   (1000, 256, 256), (777, 512, 768), (12345, 256, 512)])      # the last three and (4096, 1024, 256): 256 x 256 tiles
+def test_linear_wgrad_and_input_grad(dtype, M, N, K, monkeypatch):
     """dW = dY^T X, db = column sums (token-split MFMA kernel, two-stage sums) and dX = dY W through the forward GEMM."""
     from uformer_amd import ops
+    monkeypatch.setenv("UF_WGRAD_V4", "1")           # the 256 x 256-tile kernel on every shape it supports (by default only with >= 64 K tokens)
     x = torch.randn(M, K, generator=g(10)).to(dtype)
     dy = torch.randn(M, N, generator=g(11)).to(dtype)
     w = (torch.randn(N, K, generator=g(12)) / K ** 0.5).to(dtype)
@@ -161,6 +163,35 @@ def test_linear_wgrad_and_input_grad(dtype, M, N, K):
     assert torch.equal(dW, dW2) and torch.equal(db, db2)
     dx = ops.linear(dy.cuda(), w.t().contiguous().cuda(), torch.zeros(K).cuda())      # dX = dY W: the forward kernel, transposed weight
     assert rel(dx, rdx) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 256), (5000, 256, 1024), (2049, 768, 256)])
+def test_linear_wgrad_tile_versions_agree(dtype, M, N, K, monkeypatch):
+    """The 256 x 256-tile kernel (uf_bwd.hip linear_wgrad4) against the 128 x 128-tile one on the same operands: both add exact products in f32,
+    only the order of the partial sums differs -- and a strided dY (ld > N, as the fused qkv gradient is laid out) through the C ABI directly."""
+    from uformer_amd import _lib, ops
+    x = torch.randn(M, K, generator=g(13)).to(dtype).cuda()
+    dy = torch.randn(M, N, generator=g(14)).to(dtype).cuda()
+    monkeypatch.setenv("UF_WGRAD_V4", "1")
+    dW4, db4 = ops.linear_wgrad(dy, x)
+    monkeypatch.setenv("UF_WGRAD_V4", "0")
+    dW3, db3 = ops.linear_wgrad(dy, x)
+    monkeypatch.setenv("UF_WGRAD_V4", "1")
+    assert rel(dW4, dW3.cpu()) < 2e-6 and rel(db4, db3.cpu()) < 2e-6
+    assert not torch.equal(dW3, torch.zeros_like(dW3))
+    # strided operands: columns [N/2, N/2 + 256) of dy as a 256-wide layer's output gradient
+    if N < 512:
+        return
+    lib = _lib.load()
+    sub = dy[:, N // 2:N // 2 + 256]
+    dWs = torch.empty(256, K, dtype=torch.float32, device="cuda")
+    dbs = torch.empty(256, dtype=torch.float32, device="cuda")
+    nbytes = lib.uf_linear_wgrad_workspace_bytes(M, 256, K)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.uf_linear_wgrad(sub.data_ptr(), N, x.data_ptr(), K, dWs.data_ptr(), dbs.data_ptr(), M, 256, K, ops.uf_dtype(dtype), ws.data_ptr(), nbytes,
+                                   torch.cuda.current_stream().cuda_stream), "uf_linear_wgrad")
+    assert rel(dWs, dW3[N // 2:N // 2 + 256].cpu()) < 2e-6 and rel(dbs, db3[N // 2:N // 2 + 256].cpu()) < 2e-6
 
 
 def _attention_bwd_reference(q, k, v, bias, mask, do, heads):
@@ -612,6 +643,53 @@ def test_layernorm_bwd_fused_reads_window_order_and_adds_residual(dtype, C, shif
     dx1, dg1, db1 = ops.layernorm_bwd_fused(x, gamma, dy_raster.to(dtype), B, H, W)    # raster order, no add: the plain form on T-typed dy
     dx2, dg2, db2 = ops.layernorm_bwd(x, gamma, dy_raster.to(dtype).float())
     assert torch.equal(dx1, dx2) and torch.equal(dg1, dg2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("C", [32, 128, 512])
+@pytest.mark.parametrize("ln_windowed,cast_windowed,shift", [(False, True, 0), (False, True, 4), (True, False, 4), (True, False, 0), (False, False, 0)])
+def test_layernorm_bwd_cast_is_the_fork_of_its_dx(dtype, C, ln_windowed, cast_windowed, shift):
+    """uf_layernorm_bwd_cast: dx, dgamma, dbeta bit-identical to uf_layernorm_bwd_fused, and the second output bit-identical to uf_grad_fork of
+    that dx (per-image scales, window order with the cyclic shift): the two places the block backward uses it (LN2: token-order dy, windowed
+    copy; LN1: window-order dy, token-order copy for the preceding block)."""
+    from uformer_amd import ops
+    B, H, W = 3, 16, 24
+    M = B * H * W
+    x = (torch.randn(M, C, generator=g(130)) * 1.5 + 0.2).cuda()
+    gamma = (1 + 0.1 * torch.randn(C, generator=g(131))).cuda()
+    dy = torch.randn(M, C, generator=g(132)).to(dtype).cuda()
+    add = torch.randn(M, C, generator=g(133)).cuda()
+    scale = torch.tensor([1.25, 0.0, 1.25]).cuda()
+    for sc in (scale, None):
+        dx0, dg0, db0 = ops.layernorm_bwd_fused(x, gamma, dy, B, H, W, add=add, windowed=ln_windowed, shift=shift)
+        dx, dg, db, cast = ops.layernorm_bwd_fused(x, gamma, dy, B, H, W, add=add, windowed=ln_windowed, shift=shift,
+                                                   cast=dict(scale=sc, windowed=cast_windowed, shift=shift))
+        assert torch.equal(dx, dx0) and torch.equal(dg, dg0) and torch.equal(db, db0)
+        _, ref = ops.grad_fork(dx0, None, sc, B, H, W, dtype, windowed=cast_windowed, shift=shift)
+        assert cast.dtype == dtype and torch.equal(cast, ref)
+        assert not torch.equal(cast.float(), torch.zeros_like(cast.float()))
+
+
+def test_block_backward_with_and_without_the_fused_fork(monkeypatch):
+    """The stored-intermediates backward of a stage of blocks with the operand copies written by the LayerNorm backward kernels against the
+    same backward with separate uf_grad_fork passes: the fused kernel adds the residual gradient with one fma, so dx1 differs in the last f32
+    bit here and there and a bf16 operand made from it by one ulp -- everything agrees to bf16 rounding."""
+    from uformer_amd import spec, train
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 77).items()}
+    x = spec.synth_input(2, 128, 128, 5).cuda()
+    dy = torch.randn(2, 3, 128, 128, generator=g(140)).cuda() * 1e-3
+    drop = train.sample_drop_scales([0.3] * sum(cfg.depths), 2, "cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    outs = []
+    for fuse in (True, False):
+        monkeypatch.setattr(train, "_FUSE_FORK", fuse)
+        outs.append(train.uformer_forward_backward(x, sd, dy, cfg=cfg, dtype=torch.bfloat16, drop_scales=drop, recompute=False))
+    (y0, d0, g0), (y1, d1, g1) = outs
+    assert torch.equal(y0, y1)
+    assert rel(d0, d1.cpu()) < 2e-2                  # a last-bit difference of dx1 can move a bf16 operand by one ulp
+    assert set(g0) == set(g1)
+    worst = max((rel(g0[k], g1[k].cpu()), k) for k in g0 if g1[k].abs().max() > 0)
+    assert worst[0] < 2e-2, worst
 
 
 @pytest.mark.parametrize("dtype", MODES)

@@ -90,6 +90,7 @@ SIGNATURES = {
     "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),
     "uf_layernorm_bwd": (I, [P, I, P, P, I, P, I, P, P, I, I, P, c_size_t, P]),
     "uf_layernorm_bwd_fused": (I, [P, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, I, I, P, c_size_t, P]),
+    "uf_layernorm_bwd_cast": (I, [P, I, P, P, I, I, P, P, I, P, P, I, I, I, I, I, I, I, P, P, I, I, P, c_size_t, P]),
     "uf_linear_wgrad_workspace_bytes": (c_size_t, [I, I, I]),
     "uf_linear_wgrad": (I, [P, I, P, I, P, P, I, I, I, I, P, c_size_t, P]),
     "uf_window_attention_bwd_workspace_bytes": (c_size_t, [I, I]),

@@ -76,10 +76,20 @@ template <typename TD> __device__ __forceinline__ f32x4 load_dy4(const TD* p) { 
 }
 template <> __device__ __forceinline__ f32x4 load_dy4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// optional second output of the LayerNorm backward: mode 0 none, 1 = row tok, 2 = the window-order row of tok (H, W, shift of the partition);
+// scale: per-image factors (hw rows per image) or NULL
+template <typename TD> struct LnCast { TD* out; const float* scale; int mode, hw, H, W, shift; };
+__device__ __forceinline__ int token_to_window_row(int tok, int H, int W, int shift) {      // inverse of window_row_to_token
+    const int hw = H * W, b = tok / hw, r = tok - b * hw;
+    const int h = r / W, w = r - h * W;
+    int hs = h - shift; if (hs < 0) hs += H;
+    int ws = w - shift; if (ws < 0) ws += W;
+    return (((b * (H >> 3) + (hs >> 3)) * (W >> 3) + (ws >> 3)) << 6) + ((hs & 7) << 3) + (ws & 7);
+}
 template <int C, typename TD>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int ld_x, const float* __restrict__ gamma,
                                                             const TD* __restrict__ dy, int ld_dy, const float* __restrict__ add, float* __restrict__ dx, int ld_dx,
-                                                            float* __restrict__ partial, int rows, int win_h, int win_w, int shift) {
+                                                            float* __restrict__ partial, int rows, int win_h, int win_w, int shift, LnCast<TD> cast) {
     constexpr int LPR = (C / 4) < 64 ? (C / 4) : 64;
     constexpr int V4 = C / (4 * LPR);
     constexpr int RPB = 256 / LPR;
@@ -127,11 +137,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         s1 = allreduce<RedSum, LPR>(s1) * (1.0f / C);
         s2 = allreduce<RedSum, LPR>(s2) * (1.0f / C);
         if (live) {
+            // the copy of dx the NEXT GEMM of the backward reads (grad_fork's job, one pass over dx less): operand type, times the per-image
+            // DropPath scale of the branch it enters, at the token's own row or at its window-order row
+            const size_t crow = cast.mode == 2 ? (size_t)token_to_window_row(tok, cast.H, cast.W, cast.shift) : (size_t)tok;
+            const float cs = (cast.mode && cast.scale) ? cast.scale[mc / cast.hw] : 1.0f;
 #pragma unroll
             for (int i = 0; i < V4; ++i) {
                 f32x4 r = (d[i] * gm[i] - s1 - v[i] * s2) * rstd;
                 if (add) r = r + ad[i];
                 *reinterpret_cast<f32x4*>(dx + (size_t)tok * ld_dx + (i * LPR + sub) * 4) = r;
+                if (cast.mode) store4(cast.out + crow * C + (i * LPR + sub) * 4, r * cs);
                 adg[i] += d[i] * v[i];
                 adb[i] += d[i];
             }
@@ -184,14 +199,56 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float* __restrict
 }
 // two independent sums in one launch (weight + bias gradient of a linear layer, dgamma + dbeta of a LayerNorm): these kernels are
 // launch-latency bound (~10 us each, 560 per training step), the arithmetic per output is the same as in the single form
+// The same sum for MANY columns and few partials (the weight gradient of a wide linear layer: 1 M columns, 8 partials): a thread owns four
+// consecutive columns (16-byte loads, a wave reads 1 KiB per partial), PL p-lanes per column group add every PL-th partial in index order and
+// are then added in lane order.  With one column per thread these launches read 4 bytes per lane and were 4.5 ms of a 76 ms training step.
+template <int PL>
+__device__ __forceinline__ void column_sum_wide_block(const float* __restrict__ partial, int P, size_t stride, float* __restrict__ out, int n, int blk) {
+    constexpr int G = 256 / PL;
+    __shared__ f32x4 shw[PL][G];
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    const int j = (blk * G + g) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (j < n) {
+        const float* src = partial + j;
+        int p = pl;
+        for (; p + 7 * PL < P; p += 8 * PL) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(p + PL * u) * stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < P; p += PL) s += *reinterpret_cast<const f32x4*>(src + (size_t)p * stride);
+    }
+    if (PL > 1) {
+        shw[pl][g] = s;
+        __syncthreads();
+        if (pl == 0 && j < n) {
+            f32x4 t = shw[0][g];
+#pragma unroll
+            for (int k = 1; k < PL; ++k) t += shw[k][g];
+            *reinterpret_cast<f32x4*>(out + j) = t;
+        }
+    } else if (j < n) {
+        *reinterpret_cast<f32x4*>(out + j) = s;
+    }
+}
+// wide1: 0 = one column per thread (column_sum_block), 1 / 4 = four columns per thread with that many p-lanes
 __global__ __launch_bounds__(256) void column_sum2_kernel(const float* __restrict__ p1, int P1, size_t s1, float* __restrict__ o1, int n1, int nb1,
-                                                          const float* __restrict__ p2, int P2, size_t s2, float* __restrict__ o2, int n2) {
-    if ((int)blockIdx.x < nb1) column_sum_block(p1, P1, s1, o1, n1, blockIdx.x);      // workgroup-uniform branch (the block holds a barrier)
-    else column_sum_block(p2, P2, s2, o2, n2, blockIdx.x - nb1);
+                                                          const float* __restrict__ p2, int P2, size_t s2, float* __restrict__ o2, int n2, int wide1) {
+    if ((int)blockIdx.x < nb1) {                                                      // workgroup-uniform branches (the blocks hold barriers)
+        if (wide1 == 1) column_sum_wide_block<1>(p1, P1, s1, o1, n1, blockIdx.x);
+        else if (wide1 == 4) column_sum_wide_block<4>(p1, P1, s1, o1, n1, blockIdx.x);
+        else column_sum_block(p1, P1, s1, o1, n1, blockIdx.x);
+    } else column_sum_block(p2, P2, s2, o2, n2, blockIdx.x - nb1);
 }
 static inline void launch_column_sum2(hipStream_t st, const float* p1, int P1, size_t s1, float* o1, int n1, const float* p2, int P2, size_t s2, float* o2, int n2) {
-    const int nb1 = (n1 + 31) / 32, nb2 = (n2 + 31) / 32;
-    hipLaunchKernelGGL(column_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p1, P1, s1, o1, n1, nb1, p2, P2, s2, o2, n2);
+    static const bool narrow = getenv("UF_COLSUM_V1") != nullptr;                    // A/B: the one-column-per-thread form everywhere
+    const bool vec = !narrow && n1 % 4 == 0 && s1 % 4 == 0 && ((uintptr_t)p1 % 16) == 0 && ((uintptr_t)o1 % 16) == 0;
+    const int wide1 = !vec ? 0 : (n1 >= (1 << 18) ? 1 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0));
+    const int nb1 = wide1 ? (n1 / 4 + 256 / wide1 - 1) / (256 / wide1) : (n1 + 31) / 32, nb2 = (n2 + 31) / 32;
+    hipLaunchKernelGGL(column_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p1, P1, s1, o1, n1, nb1, p2, P2, s2, o2, n2, wide1);
 }
 constexpr int COLSUM_COLS = 32;   // columns per workgroup of column_sum_kernel
 
@@ -1034,6 +1091,147 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad3_kernel(const T* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Weight gradient, fourth version (round 4): 256 x 256 output tile per workgroup, eight waves, four-deep LDS-DMA ring.
+// linear_wgrad3 ran at 13 % of the MFMA rate on the wide layers (280-330 TFLOP/s at dec1 / dec0, profiles/r04_run11.txt) with HBM at
+// 1.4 TB/s and LDS at half its rate: every 64-token step waits for ONE step of prefetch (64 KiB in flight per CU), and a 128 x 128 tile
+// needs 512 bytes of operands per token for 32 K MACs -- the L2 -> LDS fill ran at 4.4-5 TB/s and that was the limit.  Here
+//   * the tile is 256 x 256 (wave (wn, wk) owns 64 rows x 128 columns: 32 MFMAs per 24 transposing reads): 1 KiB of operands per token
+//     for 128 K MACs, half the fill per flop;
+//   * a stage is 32 tokens = two dY panels + two X panels of [32][128] in the layout of the third version (wg2_off, so DMA placement and
+//     transposing reads are the proven ones), four stages of 32 KiB: three in flight while one is read, `s_waitcnt vmcnt(8/4/0)` counts
+//     the wave's own 4 instructions per stage, one barrier per stage;
+//   * the bias gradient is the product with a fragment of ones on the matrix pipe (4 MFMAs per stage in the wk = 0 waves of the first
+//     K tile column) instead of 70 VALU instructions per step in half of all workgroups.
+// Shapes with N or K not a multiple of 256 keep the third version.  Same partial-tile + ordered column sum as before (bit-reproducible;
+// not bit-identical to the third version: the chunking and the bias summation order differ).
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct OnesWord;
+template <> struct OnesWord<bf16> { static constexpr unsigned v = 0x3f803f80u; };
+template <> struct OnesWord<f16> { static constexpr unsigned v = 0x3c003c00u; };
+constexpr int WG4_TOK = 32, WG4_PANEL = WG4_TOK * 256, WG4_STAGE = 4 * WG4_PANEL, WG4_NST = 4;
+template <typename T>
+__global__ __launch_bounds__(512, 1) void linear_wgrad4_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ X, int ldx,
+                                                               float* __restrict__ ws_w, float* __restrict__ ws_b, int M, int N, int K, int S) {
+    __shared__ __attribute__((aligned(1024))) char smem[WG4_NST * WG4_STAGE];
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int k_tiles = K / 256, tiles = (N / 256) * k_tiles;
+    const int xcd = (int)blockIdx.x & 7, seq = (int)blockIdx.x >> 3;      // XCD x walks chunks x, x + 8, ...: see linear_wgrad2_kernel
+    const int tile = seq % tiles, chunk = (seq / tiles) * 8 + xcd;
+    if (chunk >= S) return;
+    const int n0 = (tile / k_tiles) * 256, k0 = (tile % k_tiles) * 256;
+    const int wn = wave >> 1, wk = wave & 1;
+    const bool do_bias = (tile % k_tiles) == 0 && wk == 0;               // wave-uniform
+    const int steps_all = (M + WG4_TOK - 1) / WG4_TOK;
+    const int s0 = (int)((long long)steps_all * chunk / S), s1 = (int)((long long)steps_all * (chunk + 1) / S);
+
+    lds_char* const lds = (lds_char*)&smem[0];
+    const unsigned lbase = (unsigned)(uintptr_t)lds;
+    // ---- DMA role: wave w moves rows [16 (w & 1), +16) of panel w >> 1 (panels 0, 1: dY columns n0 + 0 / + 128; 2, 3: X columns k0 + 0 / + 128),
+    // instruction q = 4 rows; lane l lands at row 4 q + l / 16, position l % 16 and fetches piece (l % 16) ^ (rho(row) << 1)
+    const int panel = wave >> 1;
+    const bool isy = panel < 2;
+    const T* src = isy ? dY : X;
+    const int ld = isy ? ldy : ldx, lim = isy ? N : K, c0 = (isy ? n0 : k0) + (panel & 1) * 128;
+    const unsigned long long sa = (unsigned long long)(uintptr_t)src;
+    const u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sa), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sa >> 32)) & 0xffffu,
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(((unsigned)(M - 1) * (unsigned)ld + (unsigned)lim) * 2u)), 0x00020000u};
+    unsigned vo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = (wave & 1) * 16 + q * 4 + (lane >> 4);
+        const int rho = (row & 3) | (((row >> 3) & 1) << 2);
+        const int pc = (lane & 15) ^ (rho << 1);
+        vo[q] = (c0 + pc * 8 < lim) ? ((unsigned)row * (unsigned)ld + (unsigned)(c0 + pc * 8)) * 2u : 0xffffff00u;
+    }
+    const unsigned drow = lbase + (unsigned)panel * WG4_PANEL + (unsigned)((wave & 1) * 16) * 256u;
+    auto issue = [&](int s) {
+        const unsigned so = (unsigned)s * (unsigned)(WG4_TOK * 2) * (unsigned)ld;
+        const unsigned db = drow + (unsigned)((s - s0) & (WG4_NST - 1)) * WG4_STAGE;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_buffer_to_lds(rs, vo[q], so, db + (unsigned)q * 1024u);
+    };
+
+    f32x4 acc[4][8], bacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    Frag<T> ones;
+    ones.v = u32x4{OnesWord<T>::v, OnesWord<T>::v, OnesWord<T>::v, OnesWord<T>::v};
+    // ---- operand addressing (as in the third version): lane (fg, fr) reads token rows 8 fg + (fr >> 2) and + 4 (= + 1024 bytes, same rho),
+    // 8-byte chunk (column / 4) + (fr & 3) of a 16-column fragment; the chunk index is XORed with rho << 2
+    const int trow = 8 * fg + (fr >> 2);
+    const int rho = (trow & 3) | (((trow >> 3) & 1) << 2);
+    unsigned ao[4], bo[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ao[i] = (unsigned)(wn >> 1) * WG4_PANEL + wg2_off(trow, (wn & 1) * 16 + i * 4 + (fr & 3));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bo[j] = (unsigned)(2 + wk) * WG4_PANEL + wg2_off(trow, j * 4 + (fr & 3));
+    (void)rho;
+    auto frag = [&](unsigned off) {
+        Frag<T> f;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off));
+        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(lds + off + 1024));
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        f.v = u32x4{l2[0], l2[1], h2[0], h2[1]};
+        return f;
+    };
+
+    const int ns = s1 - s0;
+    for (int d = 0; d < WG4_NST - 1 && d < ns; ++d) issue(s0 + d);
+    for (int s = s0; s < s1; ++s) {
+        const int rem = s1 - 1 - s;                          // stages issued after s: min(rem, 2) are still in flight behind it
+        if (rem >= 2) wait_dma<8>();
+        else if (rem == 1) wait_dma<4>();
+        else wait_dma<0>();
+        __syncthreads();                                     // stage s landed for every wave; every wave is done reading stage s - 1
+        if (s + WG4_NST - 1 < s1) issue(s + WG4_NST - 1);    // ... whose buffer this refills
+        const unsigned sb = (unsigned)((s - s0) & (WG4_NST - 1)) * WG4_STAGE;
+        Frag<T> a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = frag(sb + ao[i]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            Frag<T> b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = frag(sb + bo[h * 4 + j]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mma16(acc[i][h * 4 + j], a[i], b[j]);
+        }
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mma16(bacc[i], a[i], ones);       // D[row n][every column] = sum over the stage's tokens of dY[token][n]
+        }
+    }
+    // ---- partial tile: D row = 4 fg + reg -> n, col = fr -> k
+    float* wp = ws_w + (size_t)chunk * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 64 + i * 16 + fg * 4 + r, k = k0 + wk * 128 + j * 16 + fr;
+                wp[(size_t)n * K + k] = acc[i][j][r];
+            }
+    if (do_bias && fr == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ws_b[(size_t)chunk * N + n0 + wn * 64 + i * 16 + fg * 4 + r] = bacc[i][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Window attention backward (WindowAttention.forward, model.py:494-519, without the projections):
 //   P = softmax(q k^T + bias + mask);   dV = P^T dO;   dP = dO V^T;   dS = P o (dP - rowsum(dP o P));
 //   dq = dS k;   dk = dS^T q;   dbias[h] = sum over windows of dS        (q is the SCALED query the forward stores)
@@ -1529,8 +1727,10 @@ extern "C" size_t uf_layernorm_bwd_workspace_bytes(int rows, int C) {
     return (size_t)LN_BWD_MAX_BLOCKS * (256 / LPR) * 2 * C * sizeof(float);
 }
 
+struct LnCastArgs { void* out; const float* scale; int mode, hw, H, W, shift; };
 static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32, uf_dtype dtype, const float* add,
-                             float* dx, int ld_dx, float* dgamma, float* dbeta, int rows, int C, int win_h, int win_w, int shift, void* ws, size_t ws_bytes, void* stream) {
+                             float* dx, int ld_dx, float* dgamma, float* dbeta, int rows, int C, int win_h, int win_w, int shift, void* ws, size_t ws_bytes, void* stream,
+                             LnCastArgs ca = LnCastArgs{nullptr, nullptr, 0, 1, 8, 8, 0}) {
     UF_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && ws, UF_ERR_NULL, "%s: null pointer", fn);
     UF_REQUIRE(rows > 0 && ld_x >= C && ld_dy >= C && ld_dx >= C && ld_x % 4 == 0 && ld_dy % 4 == 0 && ld_dx % 4 == 0, UF_ERR_SHAPE,
                "%s: rows=%d C=%d ld=(%d,%d,%d)", fn, rows, C, ld_x, ld_dy, ld_dx);
@@ -1546,9 +1746,12 @@ static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const flo
         constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64, RPB = 256 / LPR;                                                   \
         const int nblk = (rows + RPB - 1) / RPB, grid = nblk < LN_BWD_MAX_BLOCKS ? nblk : LN_BWD_MAX_BLOCKS;                  \
         slots = grid * RPB;                                                                                                   \
-        if (f32dy) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, float>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const float*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
-        else if (dtype == UF_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, f16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const f16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
-        else hipLaunchKernelGGL((layernorm_bwd_kernel<CV, bf16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const bf16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift); \
+        if (f32dy) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, float>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const float*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift, \
+                                      (LnCast<float>{(float*)ca.out, ca.scale, ca.mode, ca.hw, ca.H, ca.W, ca.shift})); \
+        else if (dtype == UF_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, f16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const f16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift, \
+                                                     (LnCast<f16>{(f16*)ca.out, ca.scale, ca.mode, ca.hw, ca.H, ca.W, ca.shift})); \
+        else hipLaunchKernelGGL((layernorm_bwd_kernel<CV, bf16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const bf16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift, \
+                                (LnCast<bf16>{(bf16*)ca.out, ca.scale, ca.mode, ca.hw, ca.H, ca.W, ca.shift})); \
         break;                                                                                                                \
     }
     switch (C) {
@@ -1585,6 +1788,24 @@ extern "C" int uf_layernorm_bwd_fused(const float* x, int ld_x, const float* gam
     UF_REQUIRE(dy_is_f32 || dtype == UF_F32 || ld_dy % 8 == 0, UF_ERR_ALIGN, "uf_layernorm_bwd_fused: ld_dy=%d", ld_dy);
     return layernorm_bwd_any("uf_layernorm_bwd_fused", x, ld_x, gamma, dy, ld_dy, dy_is_f32, dtype, add, dx, ld_dx, dgamma, dbeta, B * H * W, C, windowed ? H : 0, windowed ? W : 0,
                              shift, ws, ws_bytes, stream);
+}
+
+// uf_layernorm_bwd_fused that also writes the copy of dx the next GEMM of the backward reads -- cast_out T[rows][C] = T(dx * cast_scale[image]) at
+// the token's row, or at its window-order row when cast_windowed (partition geometry H, W, cast_shift) -- which is what uf_grad_fork did in a
+// pass of its own (read dx, read the residual gradient, write both: 3.7 ms of a 76 ms Uformer-B training step, profiles/r04_run13.txt).  dy must
+// be of the operand type (dy_is_f32 = 0, or dtype = f32).  Same dx, dgamma, dbeta as uf_layernorm_bwd_fused, bit for bit.
+extern "C" int uf_layernorm_bwd_cast(const float* x, int ld_x, const float* gamma, const void* dy, int ld_dy, int dy_is_f32, const float* add, float* dx, int ld_dx,
+                                     float* dgamma, float* dbeta, int B, int H, int W, int C, int windowed, int shift, uf_dtype dtype, void* cast_out,
+                                     const float* cast_scale, int cast_windowed, int cast_shift, void* ws, size_t ws_bytes, void* stream) {
+    UF_REQUIRE(B > 0 && H > 0 && W > 0 && dtype_ok(dtype), UF_ERR_SHAPE, "uf_layernorm_bwd_cast: B=%d H=%d W=%d dtype=%d", B, H, W, (int)dtype);
+    UF_REQUIRE(dy_is_f32 || dtype == UF_F32 || ld_dy % 8 == 0, UF_ERR_ALIGN, "uf_layernorm_bwd_cast: ld_dy=%d", ld_dy);
+    UF_REQUIRE(cast_out, UF_ERR_NULL, "uf_layernorm_bwd_cast: cast_out is NULL (use uf_layernorm_bwd_fused)");
+    UF_REQUIRE(!dy_is_f32 || dtype == UF_F32, UF_ERR_UNSUPPORTED, "uf_layernorm_bwd_cast: dy must be of the operand type");
+    UF_REQUIRE(!cast_windowed || (H % 8 == 0 && W % 8 == 0 && (cast_shift == 0 || cast_shift == 4)), UF_ERR_SHAPE, "uf_layernorm_bwd_cast: window geometry H=%d W=%d shift=%d", H, W,
+               cast_shift);
+    UF_REQUIRE(((uintptr_t)cast_out % 16) == 0 && C % 4 == 0, UF_ERR_ALIGN, "uf_layernorm_bwd_cast: cast_out alignment");
+    return layernorm_bwd_any("uf_layernorm_bwd_cast", x, ld_x, gamma, dy, ld_dy, dy_is_f32, dtype, add, dx, ld_dx, dgamma, dbeta, B * H * W, C, windowed ? H : 0, windowed ? W : 0,
+                             shift, ws, ws_bytes, stream, LnCastArgs{cast_out, cast_scale, cast_windowed ? 2 : 1, H * W, H, W, cast_shift});
 }
 
 extern "C" size_t uf_dwconv3x3_wgrad_workspace_bytes(int C, uf_dtype dtype) {
@@ -1702,10 +1923,33 @@ static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     return S < 1 ? 1 : S;
 }
 
+// fourth version (256 x 256 tiles, one workgroup of 8 waves per CU): N and K multiples of 256.  Measured against the third version on the
+// Uformer-B shapes at batch 32 (profiles/r04_run12.txt, microseconds third / fourth): 131072 x 1024 x 256: 105 / 90, 131072 x 768 x 256: 125 / 121,
+// 131072 x 256 x 256: 35 / 45, 32768 x 2048 x 512: 82 / 83, 32768 x 1024 x 256: 34 / 41, 8192 x 2048 x 512: 33 / 43 -- it pays with many tokens per
+// chunk (its pipeline is three stages deep before the first MFMA, and a chunk's partial tile is four times as large), so that is where it runs.
+// UF_WGRAD_V4=0 turns it off, UF_WGRAD_V4=1 runs it on every shape it supports (A/B runs, tests).
+static bool wgrad4_shape(int M, int N, int K) {
+    const char* e = getenv("UF_WGRAD_V4");
+    if ((e && e[0] == '0') || !wgrad_v2() || N % 256 || K % 256 || M < 256) return false;
+    if (e && e[0] == '1') return true;
+    return M >= 65536 && (long long)N * K >= 196608;
+}
+static int wgrad4_chunks(int M, int N, int K) {
+    static const int target_env = getenv("UF_WGRAD4_TARGET") ? atoi(getenv("UF_WGRAD4_TARGET")) : 0;
+    const int tiles = (N / 256) * (K / 256), steps = (M + WG4_TOK - 1) / WG4_TOK;
+    int S = (target_env > 0 ? target_env : 256) / tiles;     // one workgroup per CU (128 KiB of LDS each)
+    if (S > steps / 4) S = steps / 4;                         // at least four stages per chunk
+    if (S > 256) S = 256;
+    return S < 1 ? 1 : S;
+}
+
 extern "C" size_t uf_linear_wgrad_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int s1 = wgrad_chunks(M, N, K, UF_F32), s2 = wgrad_chunks(M, N, K, UF_BF16);     // the dtype is not an argument: size for either kernel
-    return (size_t)(s1 > s2 ? s1 : s2) * ((size_t)N * K + N) * sizeof(float);
+    int s = wgrad_chunks(M, N, K, UF_F32);                                                   // the dtype is not an argument: size for any kernel
+    const int s2 = wgrad_chunks(M, N, K, UF_BF16), s4 = N % 256 == 0 && K % 256 == 0 ? wgrad4_chunks(M, N, K) : 0;
+    s = s2 > s ? s2 : s;
+    s = s4 > s ? s4 : s;
+    return (size_t)s * ((size_t)N * K + N) * sizeof(float);
 }
 
 extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, float* dW, float* db, int M, int N, int K,
@@ -1720,7 +1964,8 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     UF_REQUIRE(ws_bytes >= need, UF_ERR_WORKSPACE, "uf_linear_wgrad: workspace too small: %zu < %zu", ws_bytes, need);
     hipStream_t st = (hipStream_t)stream;
     const bool v2 = dtype_half(dtype) && wgrad_v2();
-    const int S = wgrad_chunks(M, N, K, dtype);
+    const bool v4 = v2 && wgrad4_shape(M, N, K) && ldy % 8 == 0 && ldx % 8 == 0 && ((long long)M + 64) * ldy * 2 < 0xffffff00LL && ((long long)M + 64) * ldx * 2 < 0xffffff00LL;   // + 64: the rows of the last stage past M
+    const int S = v4 ? wgrad4_chunks(M, N, K) : wgrad_chunks(M, N, K, dtype);
     float* ws_w = (float*)ws;
     float* ws_b = ws_w + (size_t)S * N * K;
     const int TT = v2 ? 128 : 64;
@@ -1733,9 +1978,12 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
         const dim3 grid2((unsigned)(grid.x * (xcd_map ? (S + 7) / 8 * 8 : S)));
         // third version (LDS-DMA staging, 64-token steps) where both operands are addressable with 32-bit byte offsets; UF_WGRAD_DMA=0: second version
         const char* e3 = getenv("UF_WGRAD_DMA");
-        const bool v3 = v2 && !(e3 && e3[0] == '0') && M >= 256 && (long long)M * ldy * 2 < 0xffffff00LL && (long long)M * ldx * 2 < 0xffffff00LL;
+        const bool v3 = v2 && !(e3 && e3[0] == '0') && M >= 256 && ((long long)M + 64) * ldy * 2 < 0xffffff00LL && ((long long)M + 64) * ldx * 2 < 0xffffff00LL;
         const dim3 grid3((unsigned)(grid.x * ((S + 7) / 8 * 8)));
-        if (v3 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad3_kernel<bf16>, grid3, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S);
+        const dim3 grid4((unsigned)((N / 256) * (K / 256) * ((S + 7) / 8 * 8)));
+        if (v4 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad4_kernel<bf16>, grid4, dim3(512), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S);
+        else if (v4) hipLaunchKernelGGL(linear_wgrad4_kernel<f16>, grid4, dim3(512), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S);
+        else if (v3 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad3_kernel<bf16>, grid3, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S);
         else if (v3) hipLaunchKernelGGL(linear_wgrad3_kernel<f16>, grid3, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S);
         else if (v2 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad2_kernel<bf16>, grid2, dim3(256), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
         else if (v2) hipLaunchKernelGGL(linear_wgrad2_kernel<f16>, grid2, dim3(256), 0, st, (const f16*)dY, ldy, (const f16*)X, ldx, ws_w, ws_b, M, N, K, S, xcd_map);
@@ -1745,7 +1993,7 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     if (rc) return rc;
     const int nk = N * K;
     if (db) launch_column_sum2(st, ws_w, S, (size_t)N * K, dW, nk, ws_b, S, (size_t)N, db, N);
-    else hipLaunchKernelGGL(column_sum_kernel, dim3((nk + COLSUM_COLS - 1) / COLSUM_COLS), dim3(256), 0, st, ws_w, S, (size_t)N * K, dW, nk);
+    else launch_column_sum2(st, ws_w, S, (size_t)N * K, dW, nk, nullptr, 0, 0, nullptr, 0);
     return check_launch("linear_wgrad_finalize");
 }
 

@@ -128,6 +128,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
 
 // dynamic LDS of a launch: two K-tile buffers, or the epilogue's staging area where that is larger (the f32 residual staging of the
 // unpadded DMA buffers: 68 KiB at BN = 128 -- still two workgroups per CU)
+#ifndef UF_GEMM_AUX_EARLY
+#define UF_GEMM_AUX_EARLY 1
+#endif
 template <typename T, int BN, int WGM, int WGN, int EP, bool DMA>
 constexpr int gemm_smem_bytes() {
     constexpr int two = 2 * (BM + BN) * (DMA ? 128 : ROWB_PAD);
@@ -180,6 +183,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     AChunk<T, AL> ra[A_CH];
     WChunk<T> rw[W_CH];
     const int nt = (p.K + BK - 1) / BK;
+
+    // E_STORE_T_MUL_DGELU: the pre-activation chunks this lane multiplies into its copy-out rows are requested HERE, before the main loop
+    // (unconditionally, from clamped addresses): at K = C the loop is 2-8 tiles long and the chunks' HBM round trip, issued in the
+    // epilogue, was an exposed 2-3 us per output tile (UF_GEMM_AUX_EARLY=0 builds the epilogue-issued form for A/B runs)
+    constexpr int AUX_CPR = (BN / WGN) * (int)sizeof(T) / 16, AUX_RPI = 64 / AUX_CPR, AUX_NIT = (BM / WGM) / AUX_RPI;
+    u32x4 auxv[EP == E_STORE_T_MUL_DGELU ? AUX_NIT : 1];
+    if constexpr (EP == E_STORE_T_MUL_DGELU && UF_GEMM_AUX_EARLY) {
+#pragma unroll
+        for (int it = 0; it < AUX_NIT; ++it) {
+            int m = m0 + wm * (BM / WGM) + it * AUX_RPI + lane / AUX_CPR, n = n0 + wn * (BN / WGN) + (lane % AUX_CPR) * EPC;
+            m = m < p.M ? m : p.M - 1;
+            n = n < p.N ? n : p.N - EPC;
+            auxv[it] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.aux) + (size_t)m * p.ldo + n);
+        }
+    }
 
     auto g_load = [&](int t) {
         const int k = t * BK + ccol * EPC;
@@ -324,8 +342,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         // E_STORE_T_MUL_DGELU: the pre-activation chunks of ALL copy-out iterations are requested here, unconditionally from clamped
         // addresses, before the barrier -- inside the guarded loop below each one was a dependent HBM round trip per iteration
         constexpr int CPR_ = WTN * (int)sizeof(T) / 16, RPI_ = 64 / CPR_, NIT_ = WTM / RPI_;
-        u32x4 auxv[EP == E_STORE_T_MUL_DGELU ? NIT_ : 1];
-        if constexpr (EP == E_STORE_T_MUL_DGELU) {
+        static_assert(EP != E_STORE_T_MUL_DGELU || (CPR_ == AUX_CPR && NIT_ == AUX_NIT), "aux chunk mapping");
+        if constexpr (EP == E_STORE_T_MUL_DGELU && !UF_GEMM_AUX_EARLY) {
 #pragma unroll
             for (int it = 0; it < NIT_; ++it) {
                 int m = mw0 + it * RPI_ + lane / CPR_, n = nw0 + (lane % CPR_) * EPC;

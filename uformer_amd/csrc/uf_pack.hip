@@ -38,6 +38,30 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
     }
 }
 
+// the four matrices AND the vectors / tables of a block in ONE launch: workgroup ranges [0, e[0]), [e[0], e[1]), ... own one job each (the
+// five launches were 3-7 us kernels, 200 per training step: 1.3 ms of a 76 ms step in profiles/r04_run13.txt)
+struct MatJob { const float *src0, *src1; int n0, N, K; void *plain, *tr, *fm; };
+template <typename T>
+__device__ __forceinline__ void pack_linear_block(const MatJob& j, int blk) {
+    const int kc = j.K / 8;
+    const long long idx = (long long)blk * 256 + threadIdx.x;
+    if (idx >= (long long)j.N * kc) return;
+    const int n = (int)(idx / kc), k = (int)(idx % kc) * 8;
+    const float* row = n < j.n0 ? j.src0 + (size_t)n * j.K : j.src1 + (size_t)(n - j.n0) * j.K;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(row + k), b = *reinterpret_cast<const f32x4*>(row + k + 4);
+    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    T *plain = (T*)j.plain, *tr = (T*)j.tr, *fm = (T*)j.fm;
+    if (plain) store8_t<T>(plain + (size_t)n * j.K + k, f);
+    if (fm) {
+        const int KS = j.K / 32;
+        store8_t<T>(fm + ((((size_t)(n >> 4) * KS + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3), f);
+    }
+    if (tr) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) store1(tr + (size_t)(k + e) * j.N + n, f[e]);
+    }
+}
+
 struct SmallPack {
     const float *qb, *kvb, *dw, *table;
     const long long* index;
@@ -63,6 +87,33 @@ __global__ __launch_bounds__(256) void pack_small_kernel(const SmallPack p) {
             p.tab[j] = p.table[(size_t)(a * 15 + (14 - b)) * p.heads + h];
         }
     }
+}
+
+__device__ __forceinline__ void pack_small_items(const SmallPack& p, int first, int stride) {
+    const int C = p.C, C4 = 4 * C;
+    const int n_b = 3 * C, n_w = 9 * C4, n_d = p.heads * 4096, n_t = p.heads * 225;
+    for (int i = first; i < n_b + 2 * n_w + n_d + n_t; i += stride) {
+        int j = i;
+        if (j < n_b) { p.bqkv[j] = j < C ? p.qb[j] : p.kvb[j - C]; continue; }
+        j -= n_b;
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9[j] = p.dw[c * 9 + t]; continue; }
+        j -= n_w;
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9_flip[j] = p.dw[c * 9 + 8 - t]; continue; }
+        j -= n_w;
+        if (j < n_d) { const int h = j >> 12, qk = j & 4095; p.dense[j] = p.table[(size_t)p.index[qk] * p.heads + h]; continue; }
+        j -= n_d;
+        { const int h = j / 225, r = j - h * 225, a = r / 15, b = r - a * 15; p.tab[j] = p.table[(size_t)(a * 15 + (14 - b)) * p.heads + h]; }
+    }
+}
+struct BlockPackJobs { MatJob m[4]; SmallPack sp; int e[4]; int n_small_blocks; };
+template <typename T>
+__global__ __launch_bounds__(256) void pack_block_kernel(const BlockPackJobs j) {
+    const int b = blockIdx.x;                                   // workgroup-uniform dispatch
+    if (b < j.e[0]) pack_linear_block<T>(j.m[0], b);
+    else if (b < j.e[1]) pack_linear_block<T>(j.m[1], b - j.e[0]);
+    else if (b < j.e[2]) pack_linear_block<T>(j.m[2], b - j.e[1]);
+    else if (b < j.e[3]) pack_linear_block<T>(j.m[3], b - j.e[2]);
+    else pack_small_items(j.sp, (b - j.e[3]) * 256 + threadIdx.x, j.n_small_blocks * 256);
 }
 
 struct PackPlan {
@@ -113,16 +164,33 @@ extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int he
     hipStream_t st = (hipStream_t)stream;
     char* b = (char*)buf;
     auto at = [&](size_t o) { return (void*)(b + o); };
-    UF_DISPATCH(dtype, TT, {
-        launch_pack_linear<TT>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
-        launch_pack_linear<TT>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
-        launch_pack_linear<TT>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
-        launch_pack_linear<TT>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
-    });
     SmallPack sp{raw->to_q_b, raw->to_kv_b, raw->dw_w, raw->rpb_table, (const long long*)raw->rpb_index,
                  (float*)at(pl.bqkv), (float*)at(pl.w9), (float*)at(pl.w9_flip), (float*)at(pl.dense), (float*)at(pl.tab), C, heads};
     const int n_small = 3 * C + 72 * C + heads * (4096 + 225);
-    hipLaunchKernelGGL(pack_small_kernel, dim3((n_small + 255) / 256), dim3(256), 0, st, sp);
+    static const bool one_launch = !(getenv("UF_PACK_LAUNCHES") && atoi(getenv("UF_PACK_LAUNCHES")) == 5);     // 5: the five-launch form (A/B runs, tests)
+    if (one_launch) {
+        BlockPackJobs j;
+        j.m[0] = MatJob{raw->to_q_w, raw->to_kv_w, C, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm)};
+        j.m[1] = MatJob{raw->proj_w, nullptr, C, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm)};
+        j.m[2] = MatJob{raw->lin1_w, nullptr, 4 * C, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm)};
+        j.m[3] = MatJob{raw->lin2_w, nullptr, C, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm)};
+        int end = 0;
+        for (int q = 0; q < 4; ++q) {
+            end += (int)(((long long)j.m[q].N * (j.m[q].K / 8) + 255) / 256);
+            j.e[q] = end;
+        }
+        j.sp = sp;
+        j.n_small_blocks = (n_small + 255) / 256;
+        UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(pack_block_kernel<TT>, dim3((unsigned)(end + j.n_small_blocks)), dim3(256), 0, st, j));
+    } else {
+        UF_DISPATCH(dtype, TT, {
+            launch_pack_linear<TT>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
+            launch_pack_linear<TT>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
+            launch_pack_linear<TT>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
+            launch_pack_linear<TT>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
+        });
+        hipLaunchKernelGGL(pack_small_kernel, dim3((n_small + 255) / 256), dim3(256), 0, st, sp);
+    }
     if (int rc = check_launch("pack_block_train")) return rc;
     if (fwd) {
         *fwd = uf_block_params{};

@@ -156,8 +156,10 @@ int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const fl
 
 // ---- backward --------------------------------------------------------------------------------------------------------------
 // LeFF half: dy -> fB = LN2-path gradient wrt x1 (WITHOUT the residual dy), parameter gradients.
+// fork_out != NULL: fB = that gradient PLUS dy (the residual path) and fork_out = T(fB * fork_scale) in window order, both written by the LN2 backward
+// kernel (uf_layernorm_bwd_cast) -- the block backward's next step, which uf_grad_fork made in a pass of its own.
 int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, const float* dy, const float* drop_leff, const uf_block_grads* g,
-                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs) {
+                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs, void* fork_out = nullptr, const float* fork_scale = nullptr) {
     const int M = B * H * W, C4 = 4 * C;
     void *st = qs.main, *sw = qs.side;
     UF_TRY(uf_grad_fork(dy, nullptr, nullptr, pl.tA, drop_leff, B, H, W, C, 0, 0, dtype, st));                          // dyT = T(dy * drop)
@@ -179,7 +181,11 @@ int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const flo
     UF_TRY(qs.fork());
     UF_TRY(uf_linear_wgrad(pl.da1, C4, pl.z, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_fwd(pl.da1, p->w1_t, pl.zero, pl.tE, M, C, C4, 0, dtype, st));                                        // dz
-    UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tE, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
+    if (fork_out)
+        UF_TRY(uf_layernorm_bwd_cast(x1, C, p->norm2_w, pl.tE, C, 0, dy, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, fork_out, fork_scale, 1, p->shift, pl.scratch,
+                                     pl.scratch_bytes, st));
+    else
+        UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tE, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
     return UF_OK;
 }
 
@@ -240,9 +246,13 @@ extern "C" int uf_lewin_block_bwd(const uf_block_train_params* p, const float* x
         UF_TRY(zero_bias(pl, C, stream));
         UF_TRY(recompute_attn(p, pl, x, drop_attn, true, B, H, W, C, dtype, stream));
         UF_TRY(recompute_leff(p, pl, pl.x1, B, H, W, C, dtype, stream));
-        UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
-        // dx1 = LN2-path gradient + dy (in place over fB), and T(dx1 * drop_attn) in window order -> dyw, one pass
-        UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
+        static const bool fuse_fork = !(getenv("UF_LN_BWD_CAST") && atoi(getenv("UF_LN_BWD_CAST")) == 0);
+        if (fuse_fork) {   // dx1 = LN2-path gradient + dy -> fB and T(dx1 * drop_attn) in window order -> dyw, from the LN2 backward kernel itself
+            UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs, pl.dyw, drop_attn));
+        } else {
+            UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
+            UF_TRY(uf_grad_fork(pl.fB, dy, pl.fB, pl.dyw, drop_attn, B, H, W, C, 1, p->shift, dtype, stream));
+        }
         return backward_attn(p, pl, x, pl.fB, dx, g, B, H, W, C, dtype, qs);
     };
     const int rc = run();

@@ -351,9 +351,12 @@ def layernorm_bwd(x: Tensor, gamma: Tensor, dy: Tensor):
     return dx.reshape(x.shape), dg, db
 
 
-def layernorm_bwd_fused(x: Tensor, gamma: Tensor, dy: Tensor, B: int, H: int, W: int, add: Optional[Tensor] = None, windowed: bool = False, shift: int = 0):
+def layernorm_bwd_fused(x: Tensor, gamma: Tensor, dy: Tensor, B: int, H: int, W: int, add: Optional[Tensor] = None, windowed: bool = False, shift: int = 0,
+                        cast: Optional[dict] = None):
     """layernorm_bwd reading dy (bf16 or f32 rows, in WINDOW order when ``windowed``) where the block backward has it, with an optional
-    second gradient ``add`` (f32) summed into dx: returns (dx f32 (B*H*W, C) raster rows, dgamma, dbeta)."""
+    second gradient ``add`` (f32) summed into dx: returns (dx f32 (B*H*W, C) raster rows, dgamma, dbeta).  ``cast`` = dict(scale=(B,) f32 or
+    None, windowed=bool, shift=int): a fourth result, (dx * scale[image]) in dy's dtype, in window order when cast['windowed'] -- the operand
+    of the next GEMM of the backward (what ``grad_fork(dx, ...)`` returns), written by the same kernel (uf_layernorm_bwd_cast)."""
     _dev(x, gamma, dy)
     Cc = x.shape[-1]
     x2, dy2 = _c(x, torch.float32).reshape(-1, Cc), _c(dy).reshape(-1, Cc)
@@ -365,10 +368,19 @@ def layernorm_bwd_fused(x: Tensor, gamma: Tensor, dy: Tensor, B: int, H: int, W:
     nbytes = lib.uf_layernorm_bwd_workspace_bytes(x2.shape[0], Cc)
     ws = _ws(nbytes, x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.uf_layernorm_bwd_fused(_ptr(x2), Cc, _ptr(_c(gamma, torch.float32)), _ptr(dy2), Cc, int(dy2.dtype == torch.float32), _ptr(add2), _ptr(dx), Cc,
-                                              _ptr(dg), _ptr(db), B, H, W, Cc, int(windowed), shift, uf_dtype(dy2.dtype), _ptr(ws), nbytes, _stream()),
-                   "uf_layernorm_bwd_fused")
-    return dx, dg, db
+        if cast is None:
+            _lib.check(lib.uf_layernorm_bwd_fused(_ptr(x2), Cc, _ptr(_c(gamma, torch.float32)), _ptr(dy2), Cc, int(dy2.dtype == torch.float32), _ptr(add2), _ptr(dx), Cc,
+                                                  _ptr(dg), _ptr(db), B, H, W, Cc, int(windowed), shift, uf_dtype(dy2.dtype), _ptr(ws), nbytes, _stream()),
+                       "uf_layernorm_bwd_fused")
+            return dx, dg, db
+        out = torch.empty(B * H * W, Cc, dtype=dy2.dtype, device=x.device)
+        scale = cast.get("scale")
+        scale = None if scale is None else _c(scale, torch.float32)
+        _lib.check(lib.uf_layernorm_bwd_cast(_ptr(x2), Cc, _ptr(_c(gamma, torch.float32)), _ptr(dy2), Cc, int(dy2.dtype == torch.float32), _ptr(add2), _ptr(dx), Cc,
+                                             _ptr(dg), _ptr(db), B, H, W, Cc, int(windowed), shift, uf_dtype(dy2.dtype), _ptr(out), _ptr(scale),
+                                             int(bool(cast.get("windowed", False))), int(cast.get("shift", 0)), _ptr(ws), nbytes, _stream()),
+                   "uf_layernorm_bwd_cast")
+    return dx, dg, db, out
 
 
 def linear_wgrad(dy: Tensor, x: Tensor, with_bias: bool = True):

@@ -226,8 +226,15 @@ class _Side:
                 self.cur.wait_stream(side)
 
 
-def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
-    """dy: (B, L, C) gradient of the block output -> (dx, gradients keyed like the reference's named_parameters())."""
+_FUSE_FORK = os.environ.get("UF_LN_BWD_CAST", "1") != "0"          # 0: separate grad_fork passes (A/B runs, tests)
+_NO_CAST = object()
+
+
+def lewin_block_backward(sv: Saved, dy: Tensor, dyT: Optional[Tensor] = None, next_scale=_NO_CAST):
+    """dy: (B, L, C) gradient of the block output -> (dx, gradients keyed like the reference's named_parameters()).
+    ``dyT``: T(dy * s2) if the caller already has it (the LayerNorm backward of the block that ran AFTER this one wrote it next to its dx).
+    ``next_scale`` (the LeFF DropPath scales (B,) of the block that ran BEFORE this one, or None for no scaling): also return
+    T(dx * next_scale) as a third result -- that block's ``dyT``."""
     p, prefix, heads, shift, T = sv["p"], sv["prefix"], sv["heads"], sv["shift"], sv["T"]
     side = _Side(dy.device)
     B, L, C = sv["shape"]
@@ -236,7 +243,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     f = lambda k: p[prefix + k]                                             # noqa: E731
     g: Grads = {}
     dyf = dy.reshape(M, C).float()
-    _, dyT = ops.grad_fork(dyf, None, sv["s2"], B, H, W, T)                  # gradient entering the (scaled) LeFF branch, as a GEMM operand
+    if dyT is None:
+        _, dyT = ops.grad_fork(dyf, None, sv["s2"], B, H, W, T)              # gradient entering the (scaled) LeFF branch, as a GEMM operand
     # LeFF: linear2 -> GELU -> depthwise -> GELU -> linear1                                   (model.py:666-685)
     g[prefix + "mlp.linear2.0.weight"], g[prefix + "mlp.linear2.0.bias"] = side.run(lambda: ops.linear_wgrad(dyT, sv["g2"]))
     pk: BlockPack = sv["pk"]
@@ -253,10 +261,14 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
         da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
     g[prefix + "mlp.linear1.0.weight"], g[prefix + "mlp.linear1.0.bias"] = side.run(lambda: ops.linear_wgrad(da1, sv["z"]))
     dz = _input_grad(da1, pk.w1_t)
-    dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W)
     # attention half: proj -> attention -> qkv -> (+modulator) -> partition/roll -> LN1              (model.py:951-986)
-    # dx1 += dy (the residual), and the (scaled) gradient entering the attention branch in window order, in one pass
-    dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
+    # dx1 = LN2-path gradient + dy (the residual), and the (scaled) gradient entering the attention branch in window order
+    if _FUSE_FORK and dz.dtype == T:                                        # both from the LayerNorm backward kernel
+        dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"], dyw = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W, add=dyf,
+                                                                                                 cast=dict(scale=sv["s1"], windowed=True, shift=shift))
+    else:
+        dx1, g[prefix + "norm2.weight"], g[prefix + "norm2.bias"] = ops.layernorm_bwd_fused(sv["x1"], f("norm2.weight"), dz, B, H, W)
+        dx1, dyw = ops.grad_fork(dx1, dyf, sv["s1"], B, H, W, T, windowed=True, shift=shift, want_sum=True)
     g[prefix + "attn.proj.weight"], g[prefix + "attn.proj.bias"] = side.run(lambda: ops.linear_wgrad(dyw, sv["o"]))
     do = _input_grad(dyw, pk.wp_t)
     dqkv, dbias = ops.window_attention_bwd_qkv(sv["q"], sv["k"], sv["vt"], pk.bias, do, H, W, shift)    # heads merged, dq times the query scale
@@ -269,8 +281,15 @@ def lewin_block_backward(sv: Saved, dy: Tensor) -> Tuple[Tensor, Grads]:
     if sv["mod"]:                                                           # the (64, C) table is added to every window
         g[prefix + "modulator.weight"] = side.run(lambda: ops.rows_sum(dxn.reshape(nW, 64 * C)).reshape(64, C))
     # LN1 backward reads dxn in window order (window_reverse + roll back folded in) and adds the residual path's gradient
+    if next_scale is not _NO_CAST and _FUSE_FORK and dxn.dtype == T:
+        dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"], dyT_next = ops.layernorm_bwd_fused(sv["x2"], f("norm1.weight"), dxn, B, H, W, add=dx1, windowed=True,
+                                                                                                     shift=shift, cast=dict(scale=next_scale, windowed=False))
+        side.join()
+        return dx.reshape(B, L, C), g, dyT_next
     dx, g[prefix + "norm1.weight"], g[prefix + "norm1.bias"] = ops.layernorm_bwd_fused(sv["x2"], f("norm1.weight"), dxn, B, H, W, add=dx1, windowed=True, shift=shift)
     side.join()
+    if next_scale is not _NO_CAST:
+        return dx.reshape(B, L, C), g, None
     return dx.reshape(B, L, C), g
 
 
@@ -472,6 +491,7 @@ class UformerTape:
             d = d.reshape(B, res[s] * res[s], C)
             names = []
             blocks = self.saved_blocks[s]
+            dyT = None                                                            # T(d * s2 of the block about to run): from the previous block's LN1 backward
             while blocks:
                 sv = blocks.pop()                                                 # frees the block's saved input as the sweep passes it
                 if "x2" not in sv:                                                # only the block input was kept: recomputation + backward in one C call
@@ -479,8 +499,11 @@ class UformerTape:
                     dxb, gv = ops.lewin_block_bwd(pk.train_params, sv["x"], d.reshape(-1, C), None if dr is None else dr[0], None if dr is None else dr[1],
                                                   B, res[s], res[s], pk.heads, T, ws=self._block_ws(s))
                     d, gb = dxb.reshape(B, res[s] * res[s], C), _named_block_grads(pk.prefix, gv, C)
+                elif blocks and "x2" in blocks[-1]:                               # the block that ran before this one reads T(d * its s2): made here
+                    d, gb, dyT = lewin_block_backward(sv, d, dyT, next_scale=blocks[-1]["s2"])
                 else:
-                    d, gb = lewin_block_backward(sv, d)
+                    d, gb = lewin_block_backward(sv, d, dyT)
+                    dyT = None
                 del sv
                 g.update(gb)
                 names.extend(gb.keys())
@@ -594,15 +617,14 @@ class NamesWithSink(list):
     sink = None
 
 
+_KEEP_PROB: Dict[tuple, Tensor] = {}
+
+
 def sample_drop_scales(rates: Sequence[float], B: int, device, generator: Optional[torch.Generator] = None) -> Tensor:
     """timm DropPath for every block in execution order: two rows (attention branch, LeFF branch) of per-sample scales
     bernoulli(1 - rate) / (1 - rate); rate 0 -> ones.  (model.py:883, :986-987; schedule :1093-1095.)"""
-    rows = []
-    for r in rates:
-        for _ in range(2):
-            if r <= 0.0:
-                rows.append(torch.ones(B, device=device))
-            else:
-                keep = 1.0 - r
-                rows.append(torch.bernoulli(torch.full((B,), keep, device=device), generator=generator) / keep)
-    return torch.stack(rows)
+    key = (tuple(float(r) for r in rates), int(B), str(device))
+    keep = _KEEP_PROB.get(key)
+    if keep is None:     # (2 * blocks, B) keep probabilities, built once: the per-block form was 3 tiny kernels per branch, 240 launches per step
+        keep = _KEEP_PROB[key] = (1.0 - torch.tensor(key[0], dtype=torch.float32).clamp(min=0.0)).repeat_interleave(2)[:, None].expand(-1, B).contiguous().to(device)
+    return torch.bernoulli(keep, generator=generator) / keep          # rate 0: bernoulli(1) / 1 = 1
