@@ -137,6 +137,11 @@ int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bias, void* ou
  *     conv AND the GELU in front of it (uf_dwconv3x3_fwd + uf_gelu_bwd in one pass). */
 int uf_dwconv3x3_pre_gelu_fwd(const void* x, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H,
                               int W, int C, uf_dtype dtype, void* stream);
+/* uf_dwconv3x3_pre_gelu_fwd on x = GELU(pre_in): pre_in T[B][H][W][C] is the PRE-activation of the GELU in front of the convolution (linear1's
+ * output, model.py:657-658); the kernel activates it as it loads it, rounded to T as a stored activation is -- bit-identical to
+ * uf_dwconv3x3_pre_gelu_fwd on the activation uf_linear_pre_gelu_fwd writes, which the training forward then need not store. */
+int uf_dwconv3x3_gelu_in_pre_gelu_fwd(const void* pre_in, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H,
+                                      int W, int C, uf_dtype dtype, void* stream);
 int uf_dwconv3x3_mul_dgelu(const void* dy, const float* w9_flipped, const void* pre, void* out, int B, int H, int W, int C,
                            uf_dtype dtype, void* stream);
 

@@ -146,6 +146,21 @@ torch.save((da.cpu(), dw.cpu(), db.cpu()), sys.argv[2])
 
 
 @pytest.mark.parametrize("dtype", MODES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 24, 64), (1, 8, 12, 32), (3, 32, 32, 128)])
+def test_dwconv_that_activates_its_input_equals_the_stencil_on_the_stored_activation(dtype, B, H, W, C):
+    """uf_dwconv3x3_gelu_in_pre_gelu_fwd(a) == uf_dwconv3x3_pre_gelu_fwd(T(GELU(a))) bit for bit (walking kernel and the one-column form):
+    the training forward stores linear1's pre-activation only."""
+    from uformer_amd import ops
+    a = (torch.randn(B, H, W, C, generator=g(150)) * 1.5).to(dtype).cuda()
+    w9 = (torch.randn(9, C, generator=g(151)) * 0.3).cuda()
+    bias = (torch.randn(C, generator=g(152)) * 0.1).cuda()
+    c0, g0 = ops.dwconv3x3_pre_gelu(ops.gelu(a), w9, bias)
+    c1, g1 = ops.dwconv3x3_pre_gelu(a, w9, bias, gelu_in=True)
+    assert torch.equal(c0, c1) and torch.equal(g0, g1)
+    assert not torch.equal(c1.float(), torch.zeros_like(c1.float()))
+
+
+@pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("M,N,K", [(1000, 128, 32), (4096, 1024, 256), (333, 48, 16), (70, 64, 64), (20000, 96, 512),
                                    (1000, 256, 256), (777, 512, 768), (12345, 256, 512)])      # the last three and (4096, 1024, 256): 256 x 256 tiles
 def test_linear_wgrad_and_input_grad(dtype, M, N, K, monkeypatch):

@@ -85,6 +85,7 @@ SIGNATURES = {
     "uf_linear_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, P]),
     "uf_linear_mul_dgelu": (I, [P, P, P, P, P, I, I, I, I, P]),
     "uf_dwconv3x3_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
+    "uf_dwconv3x3_gelu_in_pre_gelu_fwd": (I, [P, P, P, P, P, I, I, I, I, I, P]),
     "uf_dwconv3x3_mul_dgelu": (I, [P, P, P, P, I, I, I, I, I, P]),
     "uf_linear_residual_fwd": (I, [P, P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "uf_layernorm_bwd_workspace_bytes": (c_size_t, [I, I]),

@@ -240,13 +240,19 @@ __global__ __launch_bounds__(256) void column_sum2_kernel(const float* __restric
     if ((int)blockIdx.x < nb1) {                                                      // workgroup-uniform branches (the blocks hold barriers)
         if (wide1 == 1) column_sum_wide_block<1>(p1, P1, s1, o1, n1, blockIdx.x);
         else if (wide1 == 4) column_sum_wide_block<4>(p1, P1, s1, o1, n1, blockIdx.x);
+        else if (wide1 == 16) column_sum_wide_block<16>(p1, P1, s1, o1, n1, blockIdx.x);
         else column_sum_block(p1, P1, s1, o1, n1, blockIdx.x);
     } else column_sum_block(p2, P2, s2, o2, n2, blockIdx.x - nb1);
 }
 static inline void launch_column_sum2(hipStream_t st, const float* p1, int P1, size_t s1, float* o1, int n1, const float* p2, int P2, size_t s2, float* o2, int n2) {
     static const bool narrow = getenv("UF_COLSUM_V1") != nullptr;                    // A/B: the one-column-per-thread form everywhere
     const bool vec = !narrow && n1 % 4 == 0 && s1 % 4 == 0 && ((uintptr_t)p1 % 16) == 0 && ((uintptr_t)o1 % 16) == 0;
-    const int wide1 = !vec ? 0 : (n1 >= (1 << 18) ? 1 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0));
+    // p-lanes so that about 256 K threads share the work (a thread of the one-lane form walks all P partials: 4-8 dependent round trips
+    // of 8 loads on 256 workgroups); the summation order depends only on (n, P)
+    static const int lanes_env = getenv("UF_COLSUM_LANES") ? atoi(getenv("UF_COLSUM_LANES")) : 0;             // A/B: 1 = the first rule (1 / 4 lanes)
+    int wide1 = 0;
+    if (vec && lanes_env == 1) wide1 = n1 >= (1 << 18) ? 1 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0);
+    else if (vec) wide1 = n1 >= (1 << 20) ? 1 : (n1 >= (1 << 18) ? (P1 >= 8 ? 4 : 1) : (n1 >= (1 << 14) && P1 >= 32 ? 16 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0)));
     const int nb1 = wide1 ? (n1 / 4 + 256 / wide1 - 1) / (256 / wide1) : (n1 + 31) / 32, nb2 = (n2 + 31) / 32;
     hipLaunchKernelGGL(column_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p1, P1, s1, o1, n1, nb1, p2, P2, s2, o2, n2, wide1);
 }

@@ -169,6 +169,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
             const int iy = iyr < 0 ? 0 : (iyr >= H ? H - 1 : iyr);
             float f[N];
             Vec16<T>::load(xb + ((size_t)iy * W + ix) * C, f);
+            if constexpr (ACT == 4) {     // the input is the PRE-activation of the GELU in front of the convolution: activate as a stored T would read
+                gelu_n<T, N>(f);
+                round_to<T, N>(f);
+            }
             if (r == -1 || r == DW_R) {   // only the halo rows can fall outside the image
 #pragma unroll
                 for (int i = 0; i < N; ++i) f[i] = rowok ? f[i] : 0.0f;
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_gelu_kernel(const T* __restrict
             for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(auxf[r][i]);
         }
         Vec16<T>::store(out + o, acc[r]);
-        if constexpr (ACT == 2) {
+        if constexpr (ACT == 2 || ACT == 4) {
             round_to<T, N>(acc[r]);
             gelu_n<T, N>(acc[r]);
             Vec16<T>::store(aux + o, acc[r]);
@@ -246,6 +250,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict
 #pragma unroll
         for (int r = 0; r < R + 2; ++r) {
             CH::unpack(raw[r], cl[r]);
+            if constexpr (ACT == 4) {     // pre-activation in, GELU applied here (rounded as the stored activation was): linear1 need not write it
+                gelu_n<T, N>(cl[r]);
+                round_to<T, N>(cl[r]);
+            }
             const float mr = (r == 0 ? mtop : (r == R + 1 ? mbot : 1.0f)) * m;
             if (r == 0 || r == R + 1) {
 #pragma unroll
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict
             const unsigned o = ro[r + 1] + (unsigned)(dx * (int)pixb);
             if constexpr (ACT == 1) gelu_n<T, N>(acc[r]);
             *reinterpret_cast<Raw*>(ob + o) = CH::pack(acc[r]);
-            if constexpr (ACT == 2) {
+            if constexpr (ACT == 2 || ACT == 4) {
                 round_to<T, N>(acc[r]);
                 gelu_n<T, N>(acc[r]);
                 *reinterpret_cast<Raw*>(ab + o) = CH::pack(acc[r]);
@@ -743,7 +751,7 @@ void launch_dwconv(const void* x, const float* w9, const float* bias, void* out,
     const long long n = (long long)B * (H / DW_R) * W * (C / N);
     hipLaunchKernelGGL((dwconv3x3_gelu_kernel<T, ACT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const T*)x, w9, bias, (T*)out, (T*)aux, B, H, W, C);
 }
-// mode: 0 plain, 1 + GELU, 2 pre-activation + GELU (two outputs), 3 * GELU'(aux)
+// mode: 0 plain, 1 + GELU, 2 pre-activation + GELU (two outputs), 3 * GELU'(aux), 4 = 2 on GELU(x) (x is the pre-activation of the GELU in front)
 int dwconv_any(const char* fn, const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, int mode, uf_dtype dtype, void* stream) {
     UF_REQUIRE(x && w9 && out && (bias || mode == 0 || mode == 3) && (aux || mode < 2), UF_ERR_NULL, "%s: null pointer", fn);
     UF_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % DW_R == 0, UF_ERR_SHAPE, "%s: bad shape (H must be a multiple of %d)", fn, DW_R);
@@ -759,6 +767,7 @@ int dwconv_any(const char* fn, const void* x, const float* w9, const float* bias
             case 0: launch_dwconv<TT, 0>(x, w9, bias, out, aux, B, H, W, C, st); break;
             case 1: launch_dwconv<TT, 1>(x, w9, bias, out, aux, B, H, W, C, st); break;
             case 2: launch_dwconv<TT, 2>(x, w9, bias, out, aux, B, H, W, C, st); break;
+            case 4: launch_dwconv<TT, 4>(x, w9, bias, out, aux, B, H, W, C, st); break;
             default: launch_dwconv<TT, 3>(x, w9, bias, out, aux, B, H, W, C, st); break;
         }
     });
@@ -776,6 +785,14 @@ extern "C" int uf_dwconv3x3_fwd(const void* x, const float* w9, const float* bia
 extern "C" int uf_dwconv3x3_pre_gelu_fwd(const void* x, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H, int W, int C,
                                          uf_dtype dtype, void* stream) {
     return dwconv_any("uf_dwconv3x3_pre_gelu_fwd", x, w9, bias, pre_out, act_out, B, H, W, C, 2, dtype, stream);
+}
+
+// uf_dwconv3x3_pre_gelu_fwd on x = GELU(pre_in) with the activation applied as the kernel loads pre_in (rounded to T as a stored activation is:
+// bit-identical to uf_dwconv3x3_pre_gelu_fwd on the tensor uf_linear_pre_gelu_fwd wrote) -- linear1 then keeps only its pre-activation, one
+// hidden-width tensor less written per block and training step.
+extern "C" int uf_dwconv3x3_gelu_in_pre_gelu_fwd(const void* pre_in, const float* w9, const float* bias, void* pre_out, void* act_out, int B, int H, int W, int C,
+                                                 uf_dtype dtype, void* stream) {
+    return dwconv_any("uf_dwconv3x3_gelu_in_pre_gelu_fwd", pre_in, w9, bias, pre_out, act_out, B, H, W, C, 4, dtype, stream);
 }
 
 extern "C" int uf_dwconv3x3_mul_dgelu(const void* dy, const float* w9_flipped, const void* pre, void* out, int B, int H, int W, int C, uf_dtype dtype, void* stream) {

@@ -129,7 +129,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, int m, int n, f32x
 // dynamic LDS of a launch: two K-tile buffers, or the epilogue's staging area where that is larger (the f32 residual staging of the
 // unpadded DMA buffers: 68 KiB at BN = 128 -- still two workgroups per CU)
 #ifndef UF_GEMM_AUX_EARLY
-#define UF_GEMM_AUX_EARLY 1
+#define UF_GEMM_AUX_EARLY 0
 #endif
 template <typename T, int BN, int WGM, int WGN, int EP, bool DMA>
 constexpr int gemm_smem_bytes() {
@@ -184,9 +184,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     WChunk<T> rw[W_CH];
     const int nt = (p.K + BK - 1) / BK;
 
-    // E_STORE_T_MUL_DGELU: the pre-activation chunks this lane multiplies into its copy-out rows are requested HERE, before the main loop
-    // (unconditionally, from clamped addresses): at K = C the loop is 2-8 tiles long and the chunks' HBM round trip, issued in the
-    // epilogue, was an exposed 2-3 us per output tile (UF_GEMM_AUX_EARLY=0 builds the epilogue-issued form for A/B runs)
+    // E_STORE_T_MUL_DGELU, -DUF_GEMM_AUX_EARLY=1: the pre-activation chunks this lane multiplies into its copy-out rows requested HERE, before
+    // the main loop, instead of in the epilogue.  Measured on the nine Uformer-B stage shapes at batch 32 (profiles/r04_run12.txt): 7127 us
+    // against 7089 us in total, slower at six shapes (the 32 extra live registers cost more than the hidden round trip) -- not the default.
     constexpr int AUX_CPR = (BN / WGN) * (int)sizeof(T) / 16, AUX_RPI = 64 / AUX_CPR, AUX_NIT = (BM / WGM) / AUX_RPI;
     u32x4 auxv[EP == E_STORE_T_MUL_DGELU ? AUX_NIT : 1];
     if constexpr (EP == E_STORE_T_MUL_DGELU && UF_GEMM_AUX_EARLY) {

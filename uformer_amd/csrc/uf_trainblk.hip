@@ -149,8 +149,16 @@ int recompute_attn(const uf_block_train_params* p, const BlockPlan& pl, const fl
 int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, int B, int H, int W, int C, uf_dtype dtype, void* st) {
     const int M = B * H * W;
     UF_TRY(uf_layernorm_fwd(x1, C, p->norm2_w, p->norm2_b, nullptr, pl.z, B, H, W, C, 0, 0, dtype, st));
-    UF_TRY(uf_linear_pre_gelu_fwd(pl.z, p->w1, p->b1, pl.a1, pl.h1, M, 4 * C, C, dtype, st));
-    UF_TRY(uf_dwconv3x3_pre_gelu_fwd(pl.h1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
+    // linear1 keeps only its pre-activation; the stencil activates it as it loads it (UF_DW_GELU_IN=0, or the two-kernel depthwise backward that
+    // reads h1: both tensors written, the stencil reads the activation)
+    static const bool gelu_in = !(getenv("UF_DW_GELU_IN") && atoi(getenv("UF_DW_GELU_IN")) == 0) && !(getenv("UF_DW_BWD_FUSED") && atoi(getenv("UF_DW_BWD_FUSED")) == 0);
+    if (gelu_in) {
+        UF_TRY(uf_linear_fwd(pl.z, p->w1, p->b1, pl.a1, M, 4 * C, C, 0, dtype, st));
+        UF_TRY(uf_dwconv3x3_gelu_in_pre_gelu_fwd(pl.a1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
+    } else {
+        UF_TRY(uf_linear_pre_gelu_fwd(pl.z, p->w1, p->b1, pl.a1, pl.h1, M, 4 * C, C, dtype, st));
+        UF_TRY(uf_dwconv3x3_pre_gelu_fwd(pl.h1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
+    }
     return UF_OK;
 }
 
@@ -159,7 +167,7 @@ int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const fl
 // fork_out != NULL: fB = that gradient PLUS dy (the residual path) and fork_out = T(fB * fork_scale) in window order, both written by the LN2 backward
 // kernel (uf_layernorm_bwd_cast) -- the block backward's next step, which uf_grad_fork made in a pass of its own.
 int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, const float* dy, const float* drop_leff, const uf_block_grads* g,
-                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs, void* fork_out = nullptr, const float* fork_scale = nullptr) {
+                  int B, int H, int W, int C, uf_dtype dtype, Queues& qs, void* fork_out = nullptr, const float* fork_scale = nullptr, float* sum_out = nullptr) {
     const int M = B * H * W, C4 = 4 * C;
     void *st = qs.main, *sw = qs.side;
     UF_TRY(uf_grad_fork(dy, nullptr, nullptr, pl.tA, drop_leff, B, H, W, C, 0, 0, dtype, st));                          // dyT = T(dy * drop)
@@ -184,6 +192,8 @@ int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const flo
     if (fork_out)
         UF_TRY(uf_layernorm_bwd_cast(x1, C, p->norm2_w, pl.tE, C, 0, dy, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, fork_out, fork_scale, 1, p->shift, pl.scratch,
                                      pl.scratch_bytes, st));
+    else if (sum_out)      // gradient + dy (the residual path) straight into the caller's tensor: the same fused add as the forked form, bit for bit
+        UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tE, C, 0, dy, sum_out, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
     else
         UF_TRY(uf_layernorm_bwd_fused(x1, C, p->norm2_w, pl.tE, C, 0, nullptr, pl.fB, C, g->norm2_w, g->norm2_b, B, H, W, C, 0, 0, dtype, pl.scratch, pl.scratch_bytes, st));
     return UF_OK;
@@ -268,8 +278,13 @@ extern "C" int uf_leff_bwd(const uf_block_train_params* p, const float* x1, cons
     Queues qs{stream, stream, nullptr, 0};
     UF_TRY(zero_bias(pl, C, stream));
     UF_TRY(recompute_leff(p, pl, x1, B, H, W, C, dtype, stream));
-    UF_TRY(backward_leff(p, pl, x1, dy, drop_leff, g, B, H, W, C, dtype, qs));
-    return uf_residual_combine(pl.fB, dy, 1, dx1, nullptr, B, H, W, C, 0, 0, dtype, stream);                               // + the residual path
+    if (dx1 == dy) {       // in place: the sum goes through the workspace
+        UF_TRY(backward_leff(p, pl, x1, dy, drop_leff, g, B, H, W, C, dtype, qs, nullptr, nullptr, pl.fB));
+        const hipError_t e = hipMemcpyAsync(dx1, pl.fB, (size_t)B * H * W * C * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) { set_error("uf_leff_bwd: hipMemcpyAsync: %s", hipGetErrorString(e)); return UF_ERR_LAUNCH; }
+        return UF_OK;
+    }
+    return backward_leff(p, pl, x1, dy, drop_leff, g, B, H, W, C, dtype, qs, nullptr, nullptr, dx1);                       // + the residual path, in the LN2 backward's store
 }
 
 extern "C" int uf_lewin_attn_bwd(const uf_block_train_params* p, const float* x, const float* dx1, float* dx, const float* drop_attn, const uf_block_grads* g,

@@ -260,15 +260,18 @@ def dwconv3x3(x: Tensor, w9: Tensor, bias: Optional[Tensor] = None, gelu: bool =
     return out
 
 
-def dwconv3x3_pre_gelu(x: Tensor, w9: Tensor, bias: Tensor) -> Tuple[Tensor, Tensor]:
-    """(pre, GELU(pre)) of the depthwise stencil in one pass (training forward keeps both)."""
+def dwconv3x3_pre_gelu(x: Tensor, w9: Tensor, bias: Tensor, gelu_in: bool = False) -> Tuple[Tensor, Tensor]:
+    """(pre, GELU(pre)) of the depthwise stencil in one pass (training forward keeps both).  ``gelu_in``: x is the PRE-activation of the GELU in
+    front of the convolution and the kernel activates it as it loads it (uf_dwconv3x3_gelu_in_pre_gelu_fwd) -- same bits as passing the stored
+    activation."""
     _dev(x, w9, bias)
     x = _c(x)
     B, H, W, Cc = x.shape
     pre, act = torch.empty_like(x), torch.empty_like(x)
+    lib = _lib.load()
+    fn, name = (lib.uf_dwconv3x3_gelu_in_pre_gelu_fwd, "uf_dwconv3x3_gelu_in_pre_gelu_fwd") if gelu_in else (lib.uf_dwconv3x3_pre_gelu_fwd, "uf_dwconv3x3_pre_gelu_fwd")
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().uf_dwconv3x3_pre_gelu_fwd(_ptr(x), _ptr(_c(w9, torch.float32)), _ptr(_c(bias, torch.float32)), _ptr(pre), _ptr(act),
-                                                         B, H, W, Cc, uf_dtype(x.dtype), _stream()), "uf_dwconv3x3_pre_gelu_fwd")
+        _lib.check(fn(_ptr(x), _ptr(_c(w9, torch.float32)), _ptr(_c(bias, torch.float32)), _ptr(pre), _ptr(act), B, H, W, Cc, uf_dtype(x.dtype), _stream()), name)
     return pre, act
 
 

@@ -179,9 +179,14 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     # x + DropPath(window_reverse(proj(o))): the residual add, the scale and the un-partition in the projection GEMM's store   model.py:975-986
     x1 = ops.linear_residual(o, pk.wp, f("attn.proj.bias"), x2, s1, B, H, W, windowed=True, shift=shift)
     z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
-    a1, h1 = ops.linear_pre_gelu(z, pk.w1, f("mlp.linear1.0.bias"))          # pre-activation (kept for GELU') and activation, one pass
-    h1 = h1.reshape(B, H, W, 4 * C)
-    c, g2 = ops.dwconv3x3_pre_gelu(h1, pk.w9, f("mlp.dwconv.0.bias"))        # likewise for the stencil and the second GELU
+    if _GELU_IN:     # linear1 keeps only its pre-activation (the backward needs that one); the stencil activates it as it loads it
+        a1 = ops.linear(z, pk.w1, f("mlp.linear1.0.bias"))
+        h1 = None
+        c, g2 = ops.dwconv3x3_pre_gelu(a1.reshape(B, H, W, 4 * C), pk.w9, f("mlp.dwconv.0.bias"), gelu_in=True)
+    else:
+        a1, h1 = ops.linear_pre_gelu(z, pk.w1, f("mlp.linear1.0.bias"))      # pre-activation (kept for GELU') and activation, one pass
+        h1 = h1.reshape(B, H, W, 4 * C)
+        c, g2 = ops.dwconv3x3_pre_gelu(h1, pk.w9, f("mlp.dwconv.0.bias"))    # likewise for the stencil and the second GELU
     g2 = g2.reshape(M, 4 * C)
     y = None
     if need_y:
@@ -192,6 +197,7 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
 
 
 _SIDE_STREAMS: Dict[str, list] = {}
+_GELU_IN = os.environ.get("UF_DW_GELU_IN", "1") != "0"            # 0: linear1 writes pre-activation AND activation, the stencil reads the latter (A/B runs)
 _DW_BWD_FUSED = os.environ.get("UF_DW_BWD_FUSED", "1") != "0"      # 0: the two-kernel form (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad), for A/B runs
 
 
@@ -255,7 +261,8 @@ def lewin_block_backward(sv: Saved, dy: Tensor, dyT: Optional[Tensor] = None, ne
         g[prefix + "mlp.dwconv.0.weight"] = dw9.t().reshape(4 * C, 1, 3, 3)
     else:
         def _dw():
-            dw9, db = ops.dwconv3x3_wgrad(sv["h1"], dc)
+            h1 = sv["h1"] if sv["h1"] is not None else ops.gelu(sv["a1"]).reshape(B, H, W, 4 * C)
+            dw9, db = ops.dwconv3x3_wgrad(h1, dc)
             return dw9.t().reshape(4 * C, 1, 3, 3), db
         g[prefix + "mlp.dwconv.0.weight"], g[prefix + "mlp.dwconv.0.bias"] = side.run(_dw)
         da1 = ops.dwconv3x3_mul_dgelu(dc, pk.w9_flip, sv["a1"].reshape(B, H, W, 4 * C)).reshape(M, 4 * C)   # flipped-tap stencil, times GELU'(a1)
