@@ -63,14 +63,25 @@ def kernel_breakdown(model, x, steps, fn=None):
     lib = _lib.load()
     torch.cuda.synchronize()
     lib.uf_timing_enable(1)
-    if fn is not None:
-        for _ in range(steps):
-            fn()
-    else:
-        with torch.no_grad():
+    # one stream while the events are in: a kernel that shares the GPU with another stream's kernel is timed at its share of the chip (linear_wgrad
+    # 245 us inside the two-stream training step, 105 us alone: profiles/r04_run11.txt / r04_run12.txt).  The forward already runs on one stream
+    # under uf_timing_enable; this covers the weight-gradient side stream of the op-by-op backward (read per block: uformer_amd/train.py _Side)
+    keep = os.environ.get("UF_BWD_STREAMS")
+    os.environ["UF_BWD_STREAMS"] = "1"
+    try:
+        if fn is not None:
             for _ in range(steps):
-                model(x)
-    torch.cuda.synchronize()
+                fn()
+        else:
+            with torch.no_grad():
+                for _ in range(steps):
+                    model(x)
+        torch.cuda.synchronize()
+    finally:
+        if keep is None:
+            os.environ.pop("UF_BWD_STREAMS", None)
+        else:
+            os.environ["UF_BWD_STREAMS"] = keep
     lib.uf_timing_enable(0)
     buf = ctypes.create_string_buffer(1 << 16)
     lib.uf_timing_report(buf, len(buf))

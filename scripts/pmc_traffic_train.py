@@ -18,7 +18,7 @@ STEPS = 2
 def symbol(kernel):
     """rocprofv3 kernel name -> (timing symbol of bench.py's train table, counts as a launch of that symbol?)"""
     k = kernel
-    m = re.search(r"linear_wgrad[23]?_kernel<uf::(\w+)", k)
+    m = re.search(r"linear_wgrad[234]?_kernel<uf::(\w+)", k)
     if m:
         return f"linear_wgrad_{m.group(1)}", True
     if "column_sum" in k:
@@ -26,7 +26,7 @@ def symbol(kernel):
     m = re.search(r"gemm_kernel<uf::(\w+), (\d+), \d+, \d+, (\d+), (\d+)(?:, (true|false))?>", k)
     if m:
         return f"gemm_{m.group(1)}_bn{m.group(2)}_a{m.group(3)}_e{m.group(4)}" + ("_dma" if m.group(5) == "true" else ""), True
-    m = re.search(r"window_attn_bwd_kernel<uf::(\w+)", k)
+    m = re.search(r"window_attn_bwd2?_kernel<uf::(\w+)", k)
     if m:
         return f"window_attn_bwd_{m.group(1)}", True
     m = re.search(r"window_attn_kernel<uf::(\w+)", k)
@@ -42,6 +42,10 @@ def symbol(kernel):
         return "layernorm", True
     if "grad_fork" in k or "residual_combine" in k:
         return "streaming_helpers", True
+    if "pack_block_kernel" in k or "pack_linear_kernel" in k or "pack_small_kernel" in k:
+        return "operand_pack", True
+    if "adamw" in k or "found_inf" in k or "scaler_update" in k:
+        return "optimizer", True
     return "other", True
 
 
