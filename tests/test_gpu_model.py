@@ -6,7 +6,7 @@ Tolerances:
   * f32 mode AND f16 mode (IEEE half operands, the reference's own AMP type): <= 1e-3 max-abs on the restored image
     (the north-star gate).  The f16 error is predicted by oracle/bf16_budget.py (operand="f16"): 2.7e-4 on Uformer-B 256x256.
   * bf16 mode: operands rounded to 8 mantissa bits through 40 blocks; we require
-    max-abs <= 8e-3 and PSNR(hip, reference) >= 60 dB on [0,1] images (measured values are
+    max-abs <= 4e-3 (BF16_TOL: twice the measured 2.1e-3) and PSNR(hip, reference) >= 60 dB on [0,1] images (measured values are
     written to gpurun_out/parity_model.json and quoted in DESIGN.md).
 """
 import json
