@@ -419,6 +419,42 @@ def test_samplers_golden(golden, dtype):
     check("output_proj", op(t(g["xo"]).cuda()), t(g["yo"]), torch.float32)
 
 
+def test_stem_beside_mfma_kernels_of_another_stream(ops, monkeypatch):
+    """The stem on a side stream while the main stream runs kernels with MFMA waves (the GEMM, a LeWin block): the situation in which the first build of
+    the LDS-staged stem returned wrong pixels in lanes 48-63 -- its packed FMAs selected the high half of a register pair (uf_elementwise.hip, kernel
+    comment; scripts/ubench_hip/pk_opsel.hip).  Every side-stream result must equal the first form's, bit for bit."""
+    from uformer_amd import model as um
+    torch.manual_seed(0)
+    B, H, E = 8, 256, 32
+    img = torch.rand(B, 3, H, H, device="cuda")
+    w27 = (torch.randn(27, E, device="cuda") * 0.2).contiguous()
+    bias = (torch.randn(E, device="cuda") * 0.1).contiguous()
+    monkeypatch.setenv("UF_INPUT_PROJ_V2", "0")
+    ref = ops.input_proj(img, w27, bias)
+    monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")
+    side = torch.cuda.Stream()
+    ga = torch.randn(131072, 256, device="cuda").to(torch.bfloat16)
+    gw = torch.randn(1024, 256, device="cuda").to(torch.bfloat16)
+    gb = torch.zeros(1024, device="cuda")
+    blk = um.LeWinTransformerBlock(32, (H, H), 1, win_size=8, shift_size=0, modulator=True).cuda().eval()
+    xb = torch.randn(B, H * H, 32, device="cuda")
+
+    def block():
+        with torch.no_grad():
+            blk(xb, None, torch.bfloat16)
+
+    for name, fn in (("GEMM", lambda: ops.linear(ga, gw, gb)), ("LeWin block", block)):
+        bad = 0
+        for _ in range(20):
+            for _ in range(3):
+                fn()
+            with torch.cuda.stream(side):
+                y = ops.input_proj(img, w27, bias)
+            torch.cuda.synchronize()
+            bad += 0 if torch.equal(y, ref) else 1
+        assert bad == 0, f"stem beside {name}: {bad} of 20 side-stream results differ from the first form"
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 256, 256), (1, 40, 72), (3, 8, 130), (1, 13, 70)])
 def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
     """The LDS-staged stem / head kernels (round 4: input_proj2 with the image tile + weights in LDS, output_proj2 with the halo tile of
@@ -433,7 +469,7 @@ def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
         w27 = packing.pack_input_proj(w).cuda()
         monkeypatch.setenv("UF_INPUT_PROJ_V2", "0")
         ref = ops.input_proj(img, w27, bias.cuda())
-        monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")                   # opt-in form (see uf_input_proj_fwd: exact in isolation, not the default)
+        monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")                   # the default form
         got = ops.input_proj(img, w27, bias.cuda())
         assert torch.equal(got, ref), f"input_proj E={E}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
         ora = O.input_proj(img.cpu(), {"input_proj.proj.0.weight": w, "input_proj.proj.0.bias": bias})

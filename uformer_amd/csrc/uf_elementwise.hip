@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_walk_kernel(const T* __restrict
 // issues 81 loads per 432 FMAs instead of 54 per 108.  Loads are unconditional (clamped), zero padding by
 // select.  The E/4 lanes of a pixel write one contiguous token row.
 // ---------------------------------------------------------------------------------------
-constexpr int IP_PX = 4;
+constexpr int IP_PX_DEFAULT = 4;
+template <int IP_PX>
 __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict__ img, const float* __restrict__ w27,
                                                          const float* __restrict__ bias, float* __restrict__ out, int ld_o, int B,
                                                          int Cin, int H, int W, int E) {
@@ -386,15 +387,25 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 // loads per 432 x 2 packed FMAs instead of 81 loads (54 of them 4-byte broadcasts) per 216.  The E/4 lanes of a pixel still write one contiguous token row.  Same products in the same order as the first form
 // (accumulation starts at the bias, channels outer, rows, then taps): bit-identical results (tests/test_gpu_ops.py).
 // ---------------------------------------------------------------------------------------
-// UF_IP2_DBG (debugging switches of round 4): 1 = relaxed register bound, 2 = weight vectors straight from global memory (the DEFAULT: see the kernel
-// comment), 4 = zero the unused pad columns of the image tile.  With the weights staged in LDS (bit 2 off) the FIRST forward of a process under two
-// half-batch streams returned wrong pixels in the last image(s) of the side-stream part in every run (gpurun_out/r04_dbg3.txt: whole images off by
-// up to 3e-2, one forward in sixteen = the first), while the kernel alone (200 repetitions) and the one-stream model were exact; with the weight
-// vectors read where they are used -- as the first form does -- sixteen of sixteen forwards agree.  The cause is not understood (the ISA orders
-// load -> ds_write -> barrier -> ds_read correctly); the form that measured clean is the one that ships.
+// UF_IP2_DBG, compile-time switches kept from the diagnosis of round 4 (default 130 = 2 | 128): 1 relaxed register bound, 2 weight vectors straight from
+// global memory, 4 zero the unused pad columns, 8 trailing __threadfence, 16 one-dimensional grid, 32 dynamic LDS, 64 a sleep in front of the barrier,
+// 128 EVERY PIXEL VALUE IN A REGISTER OF ITS OWN (the fix), 256 a wait + 32 idle cycles behind the LDS reads.
+//
+// What was wrong.  Under the model's two half-batch streams the first builds of this kernel returned wrong pixels for the side-stream images in 2 of 10 ...
+// 10 of 10 forwards (never alone, never on one stream).  Not a stream-ordering problem: the kernel ALONE on a side stream is wrong whenever a kernel with
+// MFMA waves (the GEMM, leff2, attn_block) runs on the main stream, and exact beside ATen kernels or another stem (scripts/r04_dbg8.py,
+// profiles/r04_run17.txt); the wrong elements are columns 48..63 of a 64-pixel tile = lanes 48-63, even channels only, and only the pixels whose products
+// use element 1 of an LDS vector read.  hipcc had compiled `acc[q] += v[q + kx] * wv` into `v_pk_fma_f32 acc, wv, v[2j:2j+1], acc op_sel:[0,1,0]` (the pixel
+// value = the HIGH half of a register pair, selected for both results).  That instruction form returns a wrong LOW result in lanes 48-63 about once in 1e7
+// when an MFMA of another wave is in flight on the SIMD -- reproduced with nothing but that instruction next to a scalar reference
+// (scripts/ubench_hip/pk_opsel.hip, profiles/r04_run19.txt; `v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]` does the same, the src0-select and the
+// op_sel_hi-only broadcast forms measured clean).  Bit 128 moves every pixel value into its own register first, so only the clean `op_sel_hi:[1,0,1]`
+// broadcast form is generated: 0 wrong outputs in 210 co-run launches (profiles/r04_run18.txt), and the idle-cycle variant (256) still fails -- it is the
+// operand select, not the LDS timing.  scripts/check_isa_hazards.py / tests/test_isa_hazards.py keep the hazardous forms out of the whole library.
 #ifndef UF_IP2_DBG
-#define UF_IP2_DBG 2
+#define UF_IP2_DBG 130
 #endif
+__global__ void empty_kernel() {}
 template <int EG>                                   // lanes per pixel = E / 4 (8 for E = 32, 4 for E = 16)
 __global__ __launch_bounds__(256, (UF_IP2_DBG & 1) ? 1 : 4) void input_proj2_kernel(const float* __restrict__ img, const float* __restrict__ w27, const float* __restrict__ bias,
                                                           float* __restrict__ out, int ld_o, int B, int H, int W) {
@@ -439,7 +450,12 @@ __global__ __launch_bounds__(256, (UF_IP2_DBG & 1) ? 1 : 4) void input_proj2_ker
             const float* row = &Is[ci][wave + ky][strip * SL];
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(row), a1 = *reinterpret_cast<const f32x4*>(row + 4);
             const f32x2_t a2 = *reinterpret_cast<const f32x2_t*>(row + 8);
-            const float v[SL + 2] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1]};
+            float v[SL + 2] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], a2[0], a2[1]};
+            if (UF_IP2_DBG & 256) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");       // diagnosis: a long gap between the LDS reads and their first use
+            if (UF_IP2_DBG & 128) {                                                                                  // diagnosis / fix: every pixel value in a register of its own
+#pragma unroll
+                for (int k = 0; k < SL + 2; ++k) asm volatile("v_mov_b32 %0, %1" : "=v"(v[k]) : "v"(v[k]));
+            }
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const f32x4 wv = (UF_IP2_DBG & 2) ? *reinterpret_cast<const f32x4*>(w27 + (ci * 9 + ky * 3 + kx) * E + e) : *reinterpret_cast<const f32x4*>(&Ws[(ci * 9 + ky * 3 + kx) * E + e]);
@@ -811,26 +827,28 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
     UF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && E % 4 == 0 && ld_o >= E && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_input_proj_fwd: bad shape");
     UF_REQUIRE((long long)B * Cin * H * W < 0x7fffffffLL && (long long)Cin * 9 * E < 0x7fffffffLL, UF_ERR_SHAPE, "uf_input_proj_fwd: image too large for 32-bit indexing");
     UF_REQUIRE(H <= 65535 && B <= 65535, UF_ERR_SHAPE, "uf_input_proj_fwd: H=%d B=%d exceed the launch grid", H, B);
-    const unsigned nx = (unsigned)((W + IP_PX - 1) / IP_PX) * (unsigned)(E / 4);
+    // pixels per thread: 4 (81 loads per 432 FMAs) or 8 (117 per 864); UF_INPUT_PROJ_PX=4|8 overrides
+    static const int px_env = getenv("UF_INPUT_PROJ_PX") ? atoi(getenv("UF_INPUT_PROJ_PX")) : 0;
+    const int px = px_env == 8 || px_env == 4 ? px_env : IP_PX_DEFAULT;
+    const unsigned nx = (unsigned)((W + px - 1) / px) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
-    // The LDS-staged second form (input_proj2_kernel: 107 -> 44 us at 16 x 256 x 256, bit-identical to this form in isolation and in the one-stream model)
-    // is OPT-IN (UF_INPUT_PROJ_V2=1): with the model's default two half-batch streams -- i.e. two hardware queues -- the blocks that consume its output
-    // read STALE rows (whatever the workspace held before) for the last image(s) of a side-stream part whenever the workspace content changed since the
-    // previous forward: the first forward of a process, or a refilled workspace (scripts/r04_dbg3.py ... r04_dbg5.py, gpurun_out/r04_dbg*.txt: wrong
-    // results in 2 of 10 ... 10 of 10 forwards; never with this first form, never with one stream, never with GPU_MAX_HW_QUEUES=1; independent of static /
-    // dynamic LDS, of where the weights are read, of the register bound; a trailing __threadfence() lowers the rate and does not remove it).  The
-    // mechanism is not understood, so the form that has been exact for four rounds stays the default.
+    // The LDS-staged second form (input_proj2_kernel: 107 -> 44 us at 16 x 256 x 256, bit-identical to the first form) is the default since the
+    // packed-f32 operand-select hazard that corrupted it beside MFMA kernels was found and removed (see the kernel comment); UF_INPUT_PROJ_V2=0: first form.
     const char* e2 = getenv("UF_INPUT_PROJ_V2");
-    const bool v1 = !(e2 && e2[0] == '1');
+    const bool v1 = e2 && e2[0] == '0';
     if (!v1 && Cin == 3 && (E == 32 || E == 16) && (H + 3) / 4 <= 65535) {
         const dim3 g32 = (UF_IP2_DBG & 16) ? dim3(((W + 63) / 64) * ((H + 3) / 4) * B) : dim3((W + 63) / 64, (H + 3) / 4, B);
         const dim3 g16 = (UF_IP2_DBG & 16) ? dim3(((W + 127) / 128) * ((H + 3) / 4) * B) : dim3((W + 127) / 128, (H + 3) / 4, B);
         const int dyn = (UF_IP2_DBG & 32) ? 16384 : 0;
         if (E == 32) hipLaunchKernelGGL(input_proj2_kernel<8>, g32, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
         else hipLaunchKernelGGL(input_proj2_kernel<4>, g16, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
+        // diagnosis of the stale-row reads (see above): UF_IP2_FENCE=1 puts an empty kernel between this one and its consumer on the same stream
+        static const int fence = getenv("UF_IP2_FENCE") ? atoi(getenv("UF_IP2_FENCE")) : 0;
+        if (fence == 1) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
         return check_launch("input_proj");
     }
-    hipLaunchKernelGGL(input_proj_kernel, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
+    if (px == 8) hipLaunchKernelGGL(input_proj_kernel<8>, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
+    else hipLaunchKernelGGL(input_proj_kernel<4>, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);
     return check_launch("input_proj");
 }
 
