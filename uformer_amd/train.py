@@ -378,7 +378,8 @@ def choose_recompute(cfg, B: int, H: int, device) -> bool:
     key = (tuple(cfg.depths), cfg.embed_dim, B, H, torch.device(device).index)
     if key not in _RECOMPUTE_CHOICE:
         dims, div = cfg.stage_dims(), cfg.stage_res_div()
-        need = 60 * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
+        per_tc = 52 if _GELU_IN else 60           # bytes per token x channel of a block (measured 49.0 / 56.5 GB for Uformer-B 256^2 at batch 32); round 4: linear1's activation is not kept
+        need = per_tc * B * sum(cfg.depths[s] * (H // div[s]) ** 2 * dims[s] for s in range(9))
         free = torch.cuda.mem_get_info(device)[0] + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         choice = need > min(0.5 * free, 96e9)      # past ~100 GB the two forms measure the same (batch 64: 356 vs 357 img/s): keep the small one
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
@@ -412,7 +413,7 @@ class UformerTape:
         B, _, H, W = img.shape
         self.B, self.H = B, H
         if self.recompute is None:
-            # Keeping every intermediate of the op-by-op forward costs ~60 bytes per token x channel of every block (measured: 56 GB for
+            # Keeping every intermediate of the op-by-op forward costs ~52 bytes per token x channel of every block (measured: 49 GB for
             # Uformer-B 256^2 at batch 32 against 17 GB) and saves the recomputation in the backward: 371 vs 334 img/s on an MI355X
             # (profiles/r03_host.txt).  288 GB of HBM is there to be used: keep them while that is under half of the free memory.
             self.recompute = choose_recompute(cfg, B, H, img.device)
