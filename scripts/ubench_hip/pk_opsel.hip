@@ -14,14 +14,16 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int ITER = 16384;
-enum Form { PKFMA_PLAIN, PKFMA_S1HI_BCAST, PKFMA_S1LO_BCAST, PKFMA_S0_SWAP, PKFMA_S0HI_BCAST, PKADD_CROSS, PKMUL_S0_SWAP, PKMOV_SWAP, PKFMA_S1HI_BCAST_LDS, PKMUL_S1HI_BCAST, PKFMA_S2HI_BCAST, PKADD_S1HI_BCAST, PKFMA_S1_SWAP, NFORM };
+enum Form { PKFMA_PLAIN, PKFMA_S1HI_BCAST, PKFMA_S1LO_BCAST, PKFMA_S0_SWAP, PKFMA_S0HI_BCAST, PKADD_CROSS, PKMUL_S0_SWAP, PKMOV_SWAP, PKFMA_S1HI_BCAST_LDS, PKMUL_S1HI_BCAST, PKFMA_S2HI_BCAST, PKADD_S1HI_BCAST, PKFMA_S1_SWAP, PKFMA_S0LO_BCAST, PKFMA_S2LO_BCAST, PKMUL_S1LO_BCAST, PKADD_S1LO_BCAST, PKADD_S0LO_BCAST, NFORM };
 static const char* form_names[] = {"v_pk_fma_f32 (no op_sel)", "v_pk_fma_f32 op_sel:[0,1,0]                    (the stem's form: src1 high half to both results)",
                                    "v_pk_fma_f32 op_sel_hi:[1,0,1]                 (src1 low half to both results)", "v_pk_fma_f32 op_sel:[1,0,0] op_sel_hi:[0,1,1]  (src0 halves swapped: the depthwise walk kernels)",
                                    "v_pk_fma_f32 op_sel:[1,0,0]                    (src0 high half to both results: conv3x3_dx_walk)", "v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0]      (cross add: attn_block)",
                                    "v_pk_mul_f32 op_sel:[1,0] op_sel_hi:[0,1]      (src0 halves swapped)", "v_pk_mov_b32 op_sel:[1,0]                      (both halves from the high register)",
                                    "v_pk_fma_f32 op_sel:[0,1,0], src1 pair fresh from ds_read_b64", "v_pk_mul_f32 op_sel:[0,1]                      (src1 high half to both results)",
                                    "v_pk_fma_f32 op_sel:[0,0,1]                    (src2 high half to both results)", "v_pk_add_f32 op_sel:[0,1]                      (src1 high half to both results)",
-                                   "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]  (src1 halves swapped)"};
+                                   "v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]  (src1 halves swapped)", "v_pk_fma_f32 op_sel_hi:[0,1,1]                 (src0 low half to both results)",
+                                   "v_pk_fma_f32 op_sel_hi:[1,1,0]                 (src2 low half to both results)", "v_pk_mul_f32 op_sel_hi:[1,0]                   (src1 low half to both results)",
+                                   "v_pk_add_f32 op_sel_hi:[1,0]                   (src1 low half to both results)", "v_pk_add_f32 op_sel_hi:[0,1]                   (src0 low half to both results)"};
 
 __device__ __forceinline__ float sfma(float a, float b, float c) { float d; asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 __device__ __forceinline__ float sadd(float a, float b) { float d; asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
@@ -41,6 +43,11 @@ template <int FORM> __device__ __forceinline__ bool one(f32x2 s0, f32x2 s1, f32x
     else if constexpr (FORM == PKFMA_S2HI_BCAST) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2)); r = f32x2{sfma(s0.x, s1.x, s2.y), sfma(s0.y, s1.y, s2.y)}; }
     else if constexpr (FORM == PKADD_S1HI_BCAST) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(s0), "v"(s1)); r = f32x2{sadd(s0.x, s1.y), sadd(s0.y, s1.y)}; }
     else if constexpr (FORM == PKFMA_S1_SWAP) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2)); r = f32x2{sfma(s0.x, s1.y, s2.x), sfma(s0.y, s1.x, s2.y)}; }
+    else if constexpr (FORM == PKFMA_S0LO_BCAST) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2)); r = f32x2{sfma(s0.x, s1.x, s2.x), sfma(s0.x, s1.y, s2.y)}; }
+    else if constexpr (FORM == PKFMA_S2LO_BCAST) { asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,1,0]" : "=v"(d) : "v"(s0), "v"(s1), "v"(s2)); r = f32x2{sfma(s0.x, s1.x, s2.x), sfma(s0.y, s1.y, s2.x)}; }
+    else if constexpr (FORM == PKMUL_S1LO_BCAST) { asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(s0), "v"(s1)); r = f32x2{smul(s0.x, s1.x), smul(s0.y, s1.x)}; }
+    else if constexpr (FORM == PKADD_S1LO_BCAST) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(s0), "v"(s1)); r = f32x2{sadd(s0.x, s1.x), sadd(s0.y, s1.x)}; }
+    else if constexpr (FORM == PKADD_S0LO_BCAST) { asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "v"(s0), "v"(s1)); r = f32x2{sadd(s0.x, s1.x), sadd(s0.x, s1.y)}; }
     else {   // the stem's sequence: the src1 pair comes straight out of LDS
         f32x2 l;
         asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(l) : "v"((unsigned)(uintptr_t)(__attribute__((address_space(3))) const f32x2*)ldsp) : "memory");
@@ -104,6 +111,6 @@ int main() {
     unsigned* dbad;
     hipMalloc(&dbad, 8 * sizeof(unsigned));
 #define RUN(F) printf("%s\n", form_names[F]); run<F>(dbad);
-    RUN(PKFMA_PLAIN) RUN(PKFMA_S1HI_BCAST) RUN(PKFMA_S1LO_BCAST) RUN(PKFMA_S0_SWAP) RUN(PKFMA_S0HI_BCAST) RUN(PKADD_CROSS) RUN(PKMUL_S0_SWAP) RUN(PKMOV_SWAP) RUN(PKFMA_S1HI_BCAST_LDS) RUN(PKMUL_S1HI_BCAST) RUN(PKFMA_S2HI_BCAST) RUN(PKADD_S1HI_BCAST) RUN(PKFMA_S1_SWAP)
+    RUN(PKFMA_PLAIN) RUN(PKFMA_S1HI_BCAST) RUN(PKFMA_S1LO_BCAST) RUN(PKFMA_S0_SWAP) RUN(PKFMA_S0HI_BCAST) RUN(PKADD_CROSS) RUN(PKMUL_S0_SWAP) RUN(PKMOV_SWAP) RUN(PKFMA_S1HI_BCAST_LDS) RUN(PKMUL_S1HI_BCAST) RUN(PKFMA_S2HI_BCAST) RUN(PKADD_S1HI_BCAST) RUN(PKFMA_S1_SWAP) RUN(PKFMA_S0LO_BCAST) RUN(PKFMA_S2LO_BCAST) RUN(PKMUL_S1LO_BCAST) RUN(PKADD_S1LO_BCAST) RUN(PKADD_S0LO_BCAST)
     return 0;
 }
