@@ -444,7 +444,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes of scripts/official_run.sh -- only if they were collected on
         # exactly these kernel sources (stamp); a number from an older build would silently go stale, so it is dropped instead
         tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True)       # newest round first
-        note = "null: no PMC passes of this build (scripts/official_run_r03.sh collects them)"
+        note = "null: no PMC passes of this build (scripts/official_run_r04.sh collects them)"
         for tf in tfiles:
             try:
                 with open(tf) as f:
@@ -459,6 +459,9 @@ def main():
                 out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
                 note = ("HBM bytes per launch, FETCH_SIZE x2 + WRITE_SIZE (separate --pmc passes of this workload, same "
                         f"kernel sources: profiles/{os.path.basename(tf)}); algorithmic bytes per launch {dom['bytes'] / dom['launches']:.4g}")
+                if "mfma_busy_frac" in tr:         # the SQ passes of the same run: share of the SIMD-cycles with the MFMA pipe / the VALU busy (scripts/pmc_traffic.py)
+                    out["roofline"]["mfma_busy_frac"] = tr["mfma_busy_frac"]
+                    out["roofline"]["valu_active_frac"] = tr["valu_active_frac"]
             break
         out["roofline"]["traffic_note"] = note
         out["roofline"]["flop_per_byte"] = dom["flops"] / max(dom["bytes"], 1.0)
@@ -517,6 +520,8 @@ def main():
         sm = {"dtype": args.dtype, "img_s": round(value, 1), "ms_step": round(1e3 * elapsed / args.steps, 3), "mfma_frac_model": round(out["mfma_frac_whole_model"], 4),
               "dom_kernel": out["roofline"]["kernel"], "dom_bound": out["roofline"]["bound"], "dom_frac": round(out["roofline"]["frac"], 4),
               "dom_avg_us": round(1e3 * out["roofline"]["avg_launch_ms"], 1), "dom_traffic": out["roofline"]["traffic"],
+              "dom_mfma_busy": (round(out["roofline"]["mfma_busy_frac"], 3) if "mfma_busy_frac" in out["roofline"] else None),
+              "dom_valu_active": (round(out["roofline"]["valu_active_frac"], 3) if "valu_active_frac" in out["roofline"] else None),
               "gpu_ms_step_kernels": round(out["roofline"]["gpu_ms_per_step_all_kernels"], 3)}
         for mname in ("bf16", "f16", "f32"):
             if mname in md:

@@ -10,7 +10,7 @@ for f in parity_model parity_ops parity_grad_B_f32 parity_grad_B_bf16 parity_gra
 # kernel trace run with UF_STREAMS=1 (whole-batch launches on one stream), the configuration the library's own HIP-event timing uses.
 export UF_STREAMS=1
 bash $R/scripts/pmc_passes.sh > $O/pmc_passes.log 2>&1; grep -E "^pmc. rc" $O/pmc_passes.log
-(cd $R && python scripts/pmc_traffic.py $O $O/r04_pmc_traffic.json | head -8 && cp $O/r04_pmc_traffic.json $R/profiles/r04_pmc_traffic.json)
+(cd $R && python scripts/pmc_traffic.py $O $O/r04_pmc_traffic.json | head -8 && cp $O/r04_pmc_traffic.json $R/profiles/r04_pmc_traffic.json)   # pmc_traffic.py also reads the SQ passes A / B (MFMA pipe busy, VALU active per symbol)
 for p in A B C D E; do mv $O/pmc${p}_pmc.csv $O/r04_final_pmc${p}.csv 2>/dev/null; rm -f $O/pmc${p}_kernel_stats.csv $O/pmc${p}_gaps.txt $O/pmc${p}.log; done
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-other-modes --no-train-mode --no-720p > $O/kt.log 2>&1
 python $R/scripts/rocprof_summary.py /tmp/kt/kt_results.db $O/r04_final | tail -2
