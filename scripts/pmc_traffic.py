@@ -21,7 +21,7 @@ def symbol(kernel):
     m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)(?:, \d+)?>", kernel)                   # <T, C, NT[, LR]>
     if m:
         return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
-    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", kernel)      # <T, C, NPG, NC, NBUF, WPS[, PW]>
+    m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)?>", kernel)      # <T, C, NPG, NC, NBUF, WPS[, PW[, CP]]>
     if m:
         return f"leff2_bf16_c{m.group(1)}_np{int(m.group(6) or 4) * int(m.group(2))}_nc{m.group(3)}"
     m = re.search(r"gemm_kernel<uf::bf16, (\d+), \d+, \d+, (\d+), (\d+)(?:, (true|false))?>", kernel)     # <T, BN, WGM, WGN, AL, EP[, DMA]>
