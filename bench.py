@@ -180,6 +180,8 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
     from uformer_amd import spec
     rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
     torch.manual_seed(1234 + rank)
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()           # peak_mem_gb below is this leg's, not the inference modes' before it
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads), modulator=cfg.modulator,
                    dd_in=cfg.dd_in, compute_dtype=TORCH_DTYPE[dtype_name])
     m.load_state_dict(sd, strict=True)
