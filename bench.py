@@ -31,7 +31,9 @@ import glob
 import hashlib
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 
@@ -209,7 +211,12 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
         loss = crit(m(x), tgt)
         (scaler.scale(loss) if scaler is not None else loss).backward()
         if sink is not None:
+            # exposed exchange time: what the compute stream still waits for the collectives AFTER the last backward kernel (0 = fully hidden)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             sink.finish()
+            e1.record()
+            state.setdefault("exchange_events", []).append((e0, e1))
         gsc = sink.grad_scale if sink is not None else 1.0
         if scaler is not None:
             scaler.step(opt, grad_scale=gsc)
@@ -221,11 +228,16 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
     for _ in range(max(1, args.train_warmup)):
         step()
     torch.cuda.synchronize(); ud.barrier(); torch.cuda.synchronize()
+    state.pop("exchange_events", None)
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
         step()
     torch.cuda.synchronize(); ud.barrier()
     dt = ud.max_over_ranks(time.perf_counter() - t0, dev) / args.train_steps
+    exposed_ms = None
+    if sink is not None:
+        ev = state.pop("exchange_events", [])
+        exposed_ms = ud.max_over_ranks(sum(a_.elapsed_time(b_) for a_, b_ in ev) / max(1, len(ev)), dev)
     flops_img = 3 * 2.0 * m.flops()                        # FLOPs_train = 3 x forward
     v = world * B / dt
     out = {"workload": f"{args.arch} {args.img}x{args.img} training step (fwd + bwd + Charbonnier + AdamW), batch {B}/GPU, DropPath 0.1, synthetic data",
@@ -234,7 +246,10 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
            "loss_is_finite": bool(torch.isfinite(state["loss"]).item()),
            "loss": float(state["loss"]), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
            "mfma_frac_whole_step": v * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[dtype_name],
-           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}
+           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep",
+           "global_batch": world * B, "exchange_buckets": (len(sink.buckets) if sink is not None else 0),
+           "exchange_bytes_per_step": (sum(int(f_.numel()) * 4 for f_ in sink.flat) if sink is not None else 0),
+           "exchange_exposed_ms_per_step": exposed_ms}
     if rank == 0:
         rows = kernel_breakdown(None, None, 1, fn=step)
         sym = {}
@@ -330,6 +345,37 @@ def timed_steps(model, x, steps, warmup, ud, dev):
     return ud.max_over_ranks(t1 - t0, dev)
 
 
+def launcher_argv(n_gpus: int, port: int, bench_args):
+    """The command ``python bench.py --gpus N`` turns itself into when no torchrun environment is present: one process per GPU
+    under torch.distributed.run on this node, rendezvous on the loopback address (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(bench_args)
+
+
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def needs_self_launch(n_gpus: int, env) -> bool:
+    """True for ``python bench.py --gpus N`` (N > 1) started WITHOUT torch.distributed.run: no RANK / WORLD_SIZE in the environment."""
+    return n_gpus > 1 and "RANK" not in env and int(env.get("WORLD_SIZE", "1")) <= 1
+
+
+def self_launch(n_gpus: int, bench_args, device_count=None) -> int:
+    """Re-run this script as N ranks (one per GPU); returns the launcher's exit code.  A box with fewer than N GPUs is a clear
+    error, not a hang at the rendezvous."""
+    have = torch.cuda.device_count() if device_count is None else device_count
+    if have < n_gpus:
+        raise SystemExit(f"bench.py --gpus {n_gpus}: this node exposes {have} GPU(s) to this process "
+                         f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); run with --gpus <= {max(have, 1)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+    return subprocess.call(launcher_argv(n_gpus, free_port(), bench_args), env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,7 +390,7 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
     ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
     ap.add_argument("--no-720p", action="store_true", help="skip modes.p720 (BASELINE configs[4]: one 1280x720 frame through expand2square -> 1280x1280)")
-    ap.add_argument("--train-mode-multi", action="store_true", help="run modes.train under N > 1 too (gradient all-reduce over RCCL)")
+    ap.add_argument("--train-mode-multi", action="store_true", help="(default since round 5; kept for old command lines) run modes.train under N > 1 too")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-warmup", type=int, default=1)
@@ -352,6 +398,8 @@ def main():
     ap.add_argument("--error-budget", action="store_true", help="bf16-mode error by source through oracle/bf16_budget.py (about a CPU-minute)")
     ap.add_argument("--kernels-json", default=None, help="also write the per-kernel breakdown to this file")
     args = ap.parse_args()
+    if needs_self_launch(args.gpus, os.environ):               # `python bench.py --gpus N`: become N ranks under torch.distributed.run
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     from uformer_amd import dist as ud
     from uformer_amd import spec
@@ -382,9 +430,9 @@ def main():
             e2 = timed_steps(m2, x, steps2, 2, ud, dev)
             others[other] = (m2, e2, steps2, ud.sum_over_ranks(float((b - a) * steps2), dev))
     train_entry = None
-    # modes.train rides along at N = 1 (like cpu_baseline); under N > 1 it would add the RCCL gradient exchange to a run whose
-    # subject is the inference metric -- scripts/scale.sh / scripts/train_bench.py measure that one on its own (--train-mode-multi forces it here)
-    if not args.no_train_mode and args.arch == "Uformer_B" and (world == 1 or args.train_mode_multi):
+    # modes.train rides along at every N: under N > 1 it is the one place of the path with a collective (the bucketed gradient all-reduce
+    # over RCCL, overlapped with the reverse sweep), so a scaling run exercises it by default (--no-train-mode skips it)
+    if not args.no_train_mode and args.arch == "Uformer_B":
         train_entry = train_mode(args, cfg, sd, dev, ud, args.train_dtype)
 
     p720_entry = None
@@ -534,7 +582,9 @@ def main():
         if "train" in md:
             tr = md["train"]
             sm.update({"train_img_s": round(tr["images_per_s"], 1), "train_ms_step": round(tr["ms_per_step"], 2), "train_dtype": tr["dtype"], "train_batch": tr["batch_per_gpu"],
-                       "train_mfma_frac": round(tr["mfma_frac_whole_step"], 4), "train_peak_mem_gb": round(tr["peak_mem_gb"], 1)})
+                       "train_mfma_frac": round(tr["mfma_frac_whole_step"], 4), "train_peak_mem_gb": round(tr["peak_mem_gb"], 1),
+                       "train_global_batch": tr["global_batch"], "train_exchange_buckets": tr["exchange_buckets"],
+                       "train_exchange_exposed_ms": (round(tr["exchange_exposed_ms_per_step"], 3) if tr["exchange_exposed_ms_per_step"] is not None else None)})
             if "roofline" in tr:
                 sm.update({"train_dom_kernel": tr["roofline"]["kernel"], "train_dom_bound": tr["roofline"]["bound"], "train_dom_frac": round(tr["roofline"]["frac"], 4),
                            "train_dom_traffic": tr["roofline"].get("traffic")})
