@@ -12,9 +12,9 @@ own code so that the oracle helpers they pin (``O.psnr`` / ``O.batch_psnr`` / ``
     is read by the REFERENCE's ``load_checkpoint`` into the REFERENCE's ``Uformer`` and by ``load_optim`` / ``load_start_epoch``
     (utils/model_utils.py:23-54, loaded by file path: it imports only torch / os / collections); the fixture stores the digest of
     what the reference holds afterwards, the test rebuilds the same file and compares;
-  * ``tail_ssim``     -- ``calculate_ssim`` (utils/caculate_psnr_ssim.py:35-81) needs ``cv2.getGaussianKernel`` / ``cv2.filter2D``:
-    **cv2 is not available in the build container**, so this one is a second, independent RESTATEMENT (separable float64 loops
-    written from the reference lines, not scipy), recorded as such in the fixture (``pinned_by = "restatement"``).
+  * ``tail_ssim``     -- round 5: the reference's own ``calculate_ssim`` / ``_ssim`` (utils/caculate_psnr_ssim.py:35-81), compiled with ``ast``
+    and run with a 2-function ``cv2`` shim (``getGaussianKernel``, ``filter2D`` by OpenCV's documented semantics; cv2 is not installed
+    here) -- ``pinned_by = "reference"``; the independent separable restatement of round 3 is kept as a cross-check (1e-9).
 
 Runs only in the build container (needs /root/reference):
 
@@ -187,20 +187,53 @@ def ssim_restated(img1_chw, img2_chw):
     return float(np.array(vals).mean())
 
 
+class Cv2Shim:
+    """The two cv2 functions utils/caculate_psnr_ssim.py:35-52 calls, by OpenCV's documented semantics (cv2 itself is not installed in the
+    build container; this is the same kind of shim as the 3-symbol ``timm`` one that lets model.py import):
+      * ``getGaussianKernel(ksize, sigma)``: (ksize, 1) float64, G_i = alpha * exp(-(i - (ksize - 1) / 2)^2 / (2 sigma^2)), sum = 1
+        (ksize 11 / sigma 1.5 is outside OpenCV's fixed small-kernel tables);
+      * ``filter2D(src, -1, kernel)``: CORRELATION (no kernel flip), anchor at the kernel centre, same depth as the source,
+        default border BORDER_REFLECT_101 = scipy's ``mode="mirror"`` (the reference crops [5:-5, 5:-5], so the border never shows)."""
+
+    @staticmethod
+    def getGaussianKernel(ksize, sigma):
+        assert ksize % 2 == 1 and sigma > 0
+        i = np.arange(ksize, dtype=np.float64) - (ksize - 1) / 2.0
+        k = np.exp(-(i * i) / (2.0 * sigma * sigma))
+        return (k / k.sum()).reshape(ksize, 1)
+
+    @staticmethod
+    def filter2D(src, ddepth, kernel):
+        from scipy.ndimage import correlate
+        assert ddepth == -1
+        return correlate(src, kernel, mode="mirror")
+
+
 def make_ssim():
+    """tail_ssim: the reference's OWN ``calculate_ssim`` / ``_ssim`` / ``reorder_image`` (utils/caculate_psnr_ssim.py:35-81, :155-162), compiled from
+    the reference file's source text and run with the cv2 shim above.  The second restatement stays in the fixture as a cross-check."""
     try:
-        import cv2  # noqa: F401
+        import cv2 as real_cv2  # noqa: F401
         have_cv2 = True
     except ImportError:
-        have_cv2 = False
+        real_cv2, have_cv2 = None, False
+    ns = compile_from(os.path.join(mg.REF, "utils", "caculate_psnr_ssim.py"), ["_ssim", "calculate_ssim", "reorder_image"],
+                      {"np": np, "cv2": real_cv2 if have_cv2 else Cv2Shim, "torch": torch})
     g = torch.Generator().manual_seed(303)
     a = torch.rand(3, 3, 37, 45, generator=g)
     b = (a + 0.08 * torch.randn(3, 3, 37, 45, generator=g)).clamp(0, 1)
-    vals = [ssim_restated(x, y) for x, y in zip(a, b)]
-    save("tail_ssim", a=a, b=b, ssim=np.array(vals), cv2_available=int(have_cv2),
-         pinned_by="restatement" if not have_cv2 else "reference",
-         source="utils/caculate_psnr_ssim.py:35-81; cv2 (getGaussianKernel, filter2D) is NOT installed in the build container: the values are an "
-                "independent separable float64 restatement of those lines, not outputs of the reference function")
+    # one pair with values outside [0, 1]: the reference's (img * 255.0).round().astype(np.uint8) wraps them (:59-62)
+    a2 = torch.rand(1, 3, 24, 31, generator=g) * 1.2 - 0.1
+    b2 = a2 + 0.05 * torch.randn(1, 3, 24, 31, generator=g)
+    ref_vals = [float(ns["calculate_ssim"](x.numpy(), y.numpy(), crop_border=0, input_order="CHW")) for x, y in zip(a, b)]
+    ref_vals2 = [float(ns["calculate_ssim"](x.numpy(), y.numpy(), crop_border=0, input_order="CHW")) for x, y in zip(a2, b2)]
+    restated = [ssim_restated(x, y) for x, y in zip(a, b)]
+    assert max(abs(u - v) for u, v in zip(ref_vals, restated)) < 1e-9, (ref_vals, restated)
+    save("tail_ssim", a=a, b=b, ssim=np.array(ref_vals), a_wrap=a2, b_wrap=b2, ssim_wrap=np.array(ref_vals2), ssim_restated=np.array(restated),
+         cv2_available=int(have_cv2), pinned_by="reference",
+         source="utils/caculate_psnr_ssim.py:35-81, :155-162: the reference's own calculate_ssim / _ssim / reorder_image, ast-compiled from its source text; "
+                + ("cv2 is the installed OpenCV" if have_cv2 else
+                   "cv2.getGaussianKernel / cv2.filter2D come from a 2-function shim written from OpenCV's documented semantics (cv2 is not installed here)"))
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 arbitrary-resolution wrapper (expand2square / crop + clamp / tiled restore) and the device input pipeline (crop + rot/flip, MixUp),
 each against the reference's formula restated in the oracle or against torch's own CPU implementation."""
 import io
+import os
 
 import numpy as np
 import pytest
@@ -165,6 +166,20 @@ def test_batch_psnr_and_ssim_vs_reference_formulas():
     s = metrics.batch_SSIM(a.cuda(), b.cuda(), average=False).cpu()
     for i in range(3):
         assert abs(s[i].item() - O.ssim(a[i], b[i])) <= 1e-5, (i, s[i].item(), O.ssim(a[i], b[i]))
+
+
+def test_batch_ssim_vs_reference_calculate_ssim_fixture():
+    """uf_batch_ssim against outputs of the reference's OWN calculate_ssim (utils/caculate_psnr_ssim.py:35-81, ast-compiled with a cv2 shim by
+    tests/golden/make_golden_tail.py: tail_ssim.npz, pinned_by = "reference"), including the pair whose out-of-range values wrap."""
+    import numpy as np
+    from uformer_amd import metrics
+    gz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tail_ssim.npz"), allow_pickle=True)
+    assert str(gz["pinned_by"]) == "reference"
+    for ka, kb, kv in (("a", "b", "ssim"), ("a_wrap", "b_wrap", "ssim_wrap")):
+        a, b = torch.from_numpy(gz[ka]), torch.from_numpy(gz[kb])
+        s = metrics.batch_SSIM(a.cuda(), b.cuda(), average=False).cpu()
+        for i in range(a.shape[0]):
+            assert abs(s[i].item() - float(gz[kv][i])) <= 1e-5, (kv, i, s[i].item(), float(gz[kv][i]))
 
 
 def test_expand2square_and_crop_clamp_kernels():

@@ -366,14 +366,19 @@ def test_tail_checkpoint_read_by_the_reference_loader(golden, tmp_path):
         assert ns["optim_digest"](o2.state_dict()) == str(g[tag + "optim_digest"])  # = the reference's optimizer after load_optim
 
 
-def test_tail_ssim_against_second_restatement(golden):
-    """O.ssim (scipy valid correlation) vs an independent separable float64 restatement of utils/caculate_psnr_ssim.py:35-81.
-    cv2 is not installed in the build container (recorded in the fixture), so this row stays 'restated', not reference-run."""
+def test_tail_ssim_against_reference_calculate_ssim(golden):
+    """O.ssim vs the reference's OWN calculate_ssim / _ssim (utils/caculate_psnr_ssim.py:35-81), ast-compiled and run by
+    tests/golden/make_golden_tail.py with a 2-function cv2 shim (getGaussianKernel, filter2D; cv2 is not installed in the build
+    container) -- including a pair with out-of-range values, which the reference's uint8 conversion wraps (:59-62)."""
     g = golden("tail_ssim")
-    assert int(g["cv2_available"]) == 0 and str(g["pinned_by"]) == "restatement"
+    assert str(g["pinned_by"]) == "reference"
     a, b = t(g["a"]), t(g["b"])
     for i in range(a.shape[0]):
         assert abs(O.ssim(a[i], b[i]) - float(g["ssim"][i])) < 1e-9
+        assert abs(float(g["ssim_restated"][i]) - float(g["ssim"][i])) < 1e-9      # round 3's independent restatement agrees
+    aw, bw = t(g["a_wrap"]), t(g["b_wrap"])
+    for i in range(aw.shape[0]):
+        assert abs(O.ssim(aw[i], bw[i]) - float(g["ssim_wrap"][i])) < 1e-9
 
 
 def test_uformer_T_train_mode_every_parameter(golden):
