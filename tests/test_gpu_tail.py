@@ -155,6 +155,49 @@ def test_dynamic_loss_scaler_matches_torch_gradscaler_semantics():
     assert s2.get_scale() == scaler.get_scale() and s2.steps_taken() == 7
 
 
+def test_scaled_step_resumes_bias_correction_from_loaded_optimizer_state():
+    """a reference checkpoint carries the optimizer (per-parameter step / exp_avg / exp_avg_sq) but no scaler
+    (train/train_denoise.py:207-235).  Loading it at step N and training on under a fresh GradScaler must continue the bias corrections at
+    N + 1, and the state_dict written afterwards must carry N + k -- compared with torch.optim.AdamW doing the same on the CPU."""
+    from uformer_amd import optim as uo
+    shapes = [(17, 5), (9,), (3000,)]
+    gen = torch.Generator().manual_seed(77)
+    params = [torch.randn(*sh, generator=gen) for sh in shapes]
+    ref_p = [torch.nn.Parameter(p.clone()) for p in params]
+    ref_opt = torch.optim.AdamW(ref_p, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    grads = lambda k: [torch.randn(*sh, generator=torch.Generator().manual_seed(1000 + 10 * k + i)) for i, sh in enumerate(shapes)]   # noqa: E731
+    for k in range(5):                                                   # N = 5 steps "before the checkpoint"
+        for p_, g_ in zip(ref_p, grads(k)):
+            p_.grad = g_
+        ref_opt.step()
+    ckpt = ref_opt.state_dict()
+    got_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    opt = uo.AdamW(got_p, lr=9.9)
+    opt.load_state_dict(ckpt)                                            # moves the moments to the parameters' device, as torch's does
+    scaler = uo.GradScaler(init_scale=256.0)
+    for k in range(5, 8):                                                # three scaled steps after the resume
+        for p_, g_ in zip(got_p, grads(k)):
+            p_.grad = (g_ * 256.0).cuda()
+        scaler.step(opt); scaler.update()
+        for p_, g_ in zip(ref_p, grads(k)):
+            p_.grad = g_
+        ref_opt.step()
+        for a, b in zip(got_p, ref_p):
+            assert torch.allclose(a.detach().cpu(), b.detach(), rtol=2e-6, atol=1e-8), (k, (a.detach().cpu() - b.detach()).abs().max().item())
+    assert scaler.steps_taken() == 8
+    sd = opt.state_dict()                                                # syncs the device-side count into the per-parameter entries by itself
+    assert all(int(st["step"]) == 8 for st in sd["state"].values())
+    for p_, g_ in zip(got_p, grads(8)):                                  # and a PLAIN step afterwards continues at 9
+        p_.grad = g_.cuda()
+    opt.step()
+    for p_, g_ in zip(ref_p, grads(8)):
+        p_.grad = g_
+    ref_opt.step()
+    for a, b in zip(got_p, ref_p):
+        assert torch.allclose(a.detach().cpu(), b.detach(), rtol=2e-6, atol=1e-8)
+    assert all(int(st["step"]) == 9 for st in opt.state.values())
+
+
 def test_batch_psnr_and_ssim_vs_reference_formulas():
     from uformer_amd import metrics
     a = torch.rand(3, 3, 72, 200, generator=g(1)) * 1.3 - 0.15             # values outside [0,1]: the clamp matters

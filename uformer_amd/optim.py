@@ -20,11 +20,33 @@ class AdamW(torch.optim.Optimizer):
         if amsgrad:
             raise NotImplementedError("amsgrad is not used by the reference (train/train_denoise.py:77)")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
+        self._scaler = None            # the GradScaler whose device-side count currently carries the bias-correction step (None: state['step'] does)
+
+    def _loaded_step(self) -> int:
+        return max((int(st["step"]) for st in self.state.values() if "step" in st), default=0)
+
+    def _leave_scaled_mode(self):
+        """state['step'] becomes the authority again (one 4-byte device read): before a plain step, and before state_dict()."""
+        if self._scaler is not None:
+            self._scaler.sync_steps(self)
+            self._scaler = None
+
+    def state_dict(self):
+        # steps taken under a GradScaler are counted on the device: write them into the per-parameter 'step' entries first, so that the
+        # 'optimizer' entry of a checkpoint (train/train_denoise.py:207-235) resumes with the right bias correction under ANY AdamW
+        if self._scaler is not None:
+            self._scaler.sync_steps(self)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._scaler = None            # the loaded 'step' entries are the authority; the next scaled step seeds the scaler from them
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0, scaler: "GradScaler | None" = None):
         if scaler is not None:
             return self._step_scaled(scaler, grad_scale)
+        self._leave_scaled_mode()
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -57,7 +79,15 @@ class AdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def _step_scaled(self, scaler: "GradScaler", grad_scale: float):
         """The step under a device-resident dynamic loss scale: every parameter shares the scaler's count of steps actually taken (a skipped step does
-        not advance it), the per-parameter ``step`` entries of the state dict are refreshed from it by ``GradScaler.sync_steps``."""
+        not advance it), the per-parameter ``step`` entries of the state dict are refreshed from it by ``GradScaler.sync_steps`` (``state_dict()`` and a
+        later plain ``step()`` do that by themselves).  The first scaled step after construction, after ``load_state_dict`` or after plain steps SEEDS the
+        scaler's count from the optimizer's own ``step`` entries when they are ahead (a reference checkpoint carries the optimizer but no scaler,
+        train/train_denoise.py:207-235): bias corrections continue at step N + 1 instead of restarting at 1 on populated moments."""
+        if self._scaler is not scaler:
+            loaded = self._loaded_step()
+            if loaded > 0:
+                scaler.state[4:5].clamp_(min=float(loaded))       # device-side max: no host synchronisation
+            self._scaler = scaler
         for group in self.param_groups:
             ps, gs, ms, vs = [], [], [], []
             for p in group["params"]:
