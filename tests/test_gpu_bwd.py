@@ -351,6 +351,35 @@ def test_module_train_mode_loss_backward_with_droppath(golden, dtype):
         assert rel(params[kname[2:]].grad, t(gd[kname])) < tol, kname
 
 
+def test_use_checkpoint_takes_the_recompute_form(golden):
+    """``use_checkpoint=True`` (model.py:1056-1057: torch.utils.checkpoint around every block) selects the recompute form of the tape -- a block
+    keeps only its input -- and its gradients agree with the kept-intermediates form of the same model on the same DropPath masks."""
+    import numpy as np
+    from uformer_amd import model, spec, train
+    gd = golden("grad_model_tiny32_droppath")
+    cfg = spec.arch_config("tiny32", img_size=128)
+    x = spec.synth_input(2, 128, 128, 4321).cuda()
+    target = spec.synth_input(2, 128, 128, 4322).cuda()
+    grads, peak = {}, {}
+    for ckpt in (False, True):
+        m = model.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
+                          modulator=cfg.modulator, dd_in=cfg.dd_in, drop_path_rate=0.5, use_checkpoint=ckpt, compute_dtype=torch.bfloat16)
+        m.load_state_dict(spec.synth_state_dict(cfg, 1234), strict=True)
+        m = m.cuda().train()
+        m._drop_scales_override = torch.from_numpy(np.asarray(gd["masks"])).cuda()
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats(); base = torch.cuda.memory_allocated()
+        d = m(x) - target
+        torch.mean(torch.sqrt(d * d + 1e-6)).backward()
+        torch.cuda.synchronize()
+        peak[ckpt] = torch.cuda.max_memory_allocated() - base
+        assert train.UformerFunction.last_recompute is ckpt
+        grads[ckpt] = {n: p_.grad.float().cpu() for n, p_ in m.named_parameters() if p_.grad is not None}
+    assert grads[True].keys() == grads[False].keys()
+    worst = max((rel(grads[True][n].cuda(), grads[False][n]), n) for n in grads[True] if grads[False][n].abs().max() > 0)
+    assert worst[0] < 6e-2, worst           # both are bf16 roundings of the same gradient (GRAD_RTOL_BF16 against the reference)
+    assert peak[True] < peak[False], peak   # the point of checkpointing
+
+
 # ---- the separate GELU pass of the training forward (UF_TRAIN_SEPARATE_GELU, off by default until the training step is re-timed)
 @pytest.mark.parametrize("dtype", MODES)
 def test_gelu_fwd(dtype):

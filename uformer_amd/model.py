@@ -443,9 +443,10 @@ class Uformer(nn.Module):
                 f"win_size={self.win_size}, compute_dtype={self.compute_dtype}")
 
     # ---- packed weights ------------------------------------------------------------------
-    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters are replaced
+    def _apply(self, fn, *a, **k):   # .to() / .cuda() / .half(): parameters are replaced -- packed weights, workspaces and the cached parameter list go
         self._packed = None
         self._ws = None
+        self.__dict__.pop("_plist", None)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
@@ -462,10 +463,6 @@ class Uformer(nn.Module):
     def repack(self):
         self._packed = None
         self.__dict__.pop("_plist", None)
-
-    def _apply(self, fn, *a, **kw):
-        self.__dict__.pop("_plist", None)
-        return super()._apply(fn, *a, **kw)
 
     def _get_packed(self, device):
         self._check_not_replica()
@@ -567,9 +564,11 @@ class Uformer(nn.Module):
         sd = self.state_dict(keep_vars=True)
         names, params = list(sd.keys()), list(sd.values())
         sink = getattr(self, "grad_sink", None)
-        if sink is not None:        # gradients go straight into the all-reduce buckets as the reverse sweep finishes each stage
-            names = train.NamesWithSink(names)
-            names.sink = sink
+        # gradients go straight into the all-reduce buckets as the reverse sweep finishes each stage (sink); use_checkpoint=True
+        # (model.py:1056-1057: torch.utils.checkpoint around every block) = the recompute form: a block keeps only its input
+        names = train.NamesWithSink(names)
+        names.sink = sink
+        names.recompute = True if self.use_checkpoint else None
         rates = self.drop_path_rates() if self.training else []      # eval(): DropPath is the identity (timm)
         drop = getattr(self, "_drop_scales_override", None) if self.training else None
         if drop is None and any(r > 0 for r in rates):

@@ -581,9 +581,11 @@ class UformerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, cfg, dtype, drop_scales, names, *params):
         sink = names.sink if isinstance(names, NamesWithSink) else None
+        recompute = names.recompute if isinstance(names, NamesWithSink) else None
         sd = {n: p.detach() for n, p in zip(names, params)}
-        tape = UformerTape(sd, cfg, dtype, drop_scales, on_stage_done=None if sink is None else sink.deliver)
+        tape = UformerTape(sd, cfg, dtype, drop_scales, recompute=recompute, on_stage_done=None if sink is None else sink.deliver)
         y = tape.forward(img.detach().float().contiguous())
+        UformerFunction.last_recompute = bool(tape.recompute)      # which form the last forward took (tests, logging)
         ctx.tape, ctx.names, ctx.sink = tape, names, sink
         ctx.img_needs_grad = img.requires_grad
         return y
@@ -621,8 +623,11 @@ class LeWinBlockFunction(torch.autograd.Function):
 
 
 class NamesWithSink(list):
-    """parameter names + the gradient sink (uformer_amd.dist.OverlappedGradientAllReduce) the tape delivers to during backward"""
+    """parameter names + the gradient sink (uformer_amd.dist.OverlappedGradientAllReduce) the tape delivers to during backward + the
+    recompute choice (True: ``use_checkpoint=True`` was given to the constructor, as the reference's torch.utils.checkpoint per block,
+    model.py:1056-1057; None: decided from the batch and the free memory)"""
     sink = None
+    recompute = None
 
 
 _KEEP_PROB: Dict[tuple, Tensor] = {}
