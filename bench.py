@@ -146,6 +146,53 @@ def cpu_baseline(arch, img, budget_s=28.0):
     return out, (x1, ref)
 
 
+def vendor_baseline(arch, img, batch, dev, x1=None, ref=None):
+    """Same-node calibration (VERDICT r04 "next" 5): the reference's op sequence on the vendor stack of THIS box -- PyTorch-ROCm eager
+    (hipBLASLt / rocBLAS linears, MIOpen convolutions, ATen LayerNorm / GELU / softmax / permutes), oracle/vendor_forward.py -- at the
+    headline batch, fp32 and under bf16 autocast, outside every timed region of the hand-written path.  Not the oracle and not a target:
+    it answers "does the hand-written HIP path beat PyTorch-ROCm on this forward on this GPU"."""
+    from oracle import vendor_forward as V
+    from uformer_amd import spec
+    cfg = spec.arch_config(arch, img_size=img)
+    sd = {k: v.to(dev) for k, v in spec.synth_state_dict(cfg, 1234).items()}
+    x = spec.synth_input(batch, img, img, 1234).to(dev)
+    kw = dict(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    out = {"what": f"oracle/vendor_forward.py: the reference forward (model.py:1269-1305 op sequence) in PyTorch-ROCm eager on this GPU, {arch} {img}x{img} batch {batch}",
+           "torch": torch.__version__, "hip": getattr(torch.version, "hip", None), "unit": "images/s"}
+    for name, ctx in (("fp32", None), ("bf16_autocast", torch.bfloat16), ("f16_autocast", torch.float16)):
+        try:
+            def run():
+                with torch.no_grad():
+                    if ctx is None:
+                        return V.forward(x, sd, **kw)
+                    with torch.autocast("cuda", dtype=ctx):
+                        return V.forward(x, sd, **kw)
+            for _ in range(2):
+                y = run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 3
+            for _ in range(n):
+                y = run()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            ent = {"images_per_s": batch / dt, "ms_per_step": 1e3 * dt, "steps": n}
+            if x1 is not None and ref is not None:       # its own error against the CPU oracle on the parity image
+                with torch.no_grad():
+                    if ctx is None:
+                        y1 = V.forward(x1.to(dev), sd, **kw)
+                    else:
+                        with torch.autocast("cuda", dtype=ctx):
+                            y1 = V.forward(x1.to(dev), sd, **kw)
+                ent["max_abs_err_vs_oracle"] = float((y1.float().cpu() - ref).abs().max())
+            out[name] = ent
+            del y
+        except Exception as e:   # noqa: BLE001 -- a vendor-library failure must not take the bench line down
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def cpu_train_baseline(arch, img, batch=2, steps=1, warmup=0):
     """BASELINE configs[2] on the host: the oracle forward under torch autograd + the reference's criterion and optimizer
     (Charbonnier eps 1e-3, torch.optim.AdamW 2e-4 / 0.02), batch 2.  One step is ~15 s on 8 cores, so the default is ONE timed step
@@ -386,6 +433,7 @@ def main():
     ap.add_argument("--img", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vendor-baseline", action="store_true", help="skip the same-node PyTorch-ROCm eager calibration (oracle/vendor_forward.py)")
     ap.add_argument("--no-f32-mode", action="store_true", help="skip the exact-f32 mode")
     ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
     ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
@@ -554,6 +602,8 @@ def main():
                 out["modes"][mname].update(out["parity"][mname])
             out["parity"]["max_abs_err_vs_oracle"] = out["parity"][args.dtype]["max_abs_err_vs_oracle"]
             out["parity"]["psnr_db_vs_oracle"] = out["parity"][args.dtype]["psnr_db_vs_oracle"]
+            if not args.no_vendor_baseline:
+                out["vendor_baseline"] = vendor_baseline(args.arch, args.img, args.batch, dev, x1, ref)
             if train_entry is not None:
                 train_entry["cpu_baseline"] = cpu_train_baseline(args.arch, args.img)
             if args.error_budget:
@@ -592,6 +642,10 @@ def main():
                 sm["train_cpu_img_s"] = round(tr["cpu_baseline"]["value"], 3)
         if "p720" in md:
             sm.update({"p720_ms": round(md["p720"]["ms_per_frame"], 2), "p720_fps": round(md["p720"]["frames_per_s"], 1), "p720_mfma_frac": round(md["p720"]["mfma_frac"], 4)})
+        if "vendor_baseline" in out:
+            for k_ in ("fp32", "bf16_autocast", "f16_autocast"):
+                if "images_per_s" in out["vendor_baseline"].get(k_, {}):
+                    sm["vendor_" + k_ + "_img_s"] = round(out["vendor_baseline"][k_]["images_per_s"], 1)
         if "cpu_baseline" in out:
             sm.update({"cpu_img_s": round(out["cpu_baseline"]["value"], 3), "cpu_cores": out["cpu_baseline"]["cores"], "cpu_kind": out["cpu_baseline"]["kind"]})
         out["summary"] = sm

@@ -366,6 +366,18 @@ def test_tail_checkpoint_read_by_the_reference_loader(golden, tmp_path):
         assert ns["optim_digest"](o2.state_dict()) == str(g[tag + "optim_digest"])  # = the reference's optimizer after load_optim
 
 
+def test_vendor_forward_equals_oracle():
+    """oracle/vendor_forward.py (the reference's op sequence on torch's library ops; bench.py times it on the GPU box as the same-node
+    vendor-stack calibration) is the same function as the oracle: tiny32 128x128, shifted and decoder (modulator) blocks included."""
+    from oracle import vendor_forward as V
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 1234)
+    x = spec.synth_input(2, 128, 128, 1234)
+    kw = dict(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    with torch.no_grad():
+        assert (O.uformer_forward(x, sd, **kw) - V.forward(x, sd, **kw)).abs().max().item() < 1e-5
+
+
 def test_tail_ssim_against_reference_calculate_ssim(golden):
     """O.ssim vs the reference's OWN calculate_ssim / _ssim (utils/caculate_psnr_ssim.py:35-81), ast-compiled and run by
     tests/golden/make_golden_tail.py with a 2-function cv2 shim (getGaussianKernel, filter2D; cv2 is not installed in the build
