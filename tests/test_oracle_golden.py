@@ -366,6 +366,36 @@ def test_tail_checkpoint_read_by_the_reference_loader(golden, tmp_path):
         assert ns["optim_digest"](o2.state_dict()) == str(g[tag + "optim_digest"])  # = the reference's optimizer after load_optim
 
 
+def test_training_trajectory_oracle_loop_reproduces_reference(golden):
+    """8 steps of the reference's loop (train/train_denoise.py:175-184: zero_grad / forward / CharbonnierLoss / backward / AdamW step; fixture from
+    the reference's own model + loss + torch.optim.AdamW with recorded DropPath masks, tests/golden/make_golden_traj.py) replayed with the oracle
+    forward under autograd: the loss of every step and the weight change of every parameter."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import gradproj
+    g = golden("traj_tiny32_8steps")
+    cfg = spec.arch_config("tiny32", img_size=128)
+    sd = spec.synth_state_dict(cfg, 1234)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for v in params.values() if v.requires_grad], lr=float(g["lr"]), betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)
+    kw = dict(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=cfg.depths, num_heads=cfg.num_heads, dd_in=cfg.dd_in)
+    xs = [spec.synth_input(2, 128, 128, 9000 + i) for i in range(2)]
+    ts = [spec.synth_input(2, 128, 128, 9100 + i) for i in range(2)]
+    for k in range(int(g["steps"])):
+        opt.zero_grad()
+        loss = O.charbonnier_loss(O.uformer_forward(xs[k % 2], params, drop_scales=t(g["masks"][k]), **kw), ts[k % 2])
+        loss.backward()
+        opt.step()
+        assert abs(float(loss.detach()) - float(g["losses"][k])) < 1e-5 * float(g["losses"][k]), k
+    for i, n in enumerate(str(n_) for n_ in g["param_names"]):
+        d = params[n].detach() - sd[n]
+        scale = float(g["delta_max"][i]) * d.numel() ** 0.5                 # size of a projection of an O(delta_max) tensor
+        for j in range(2):
+            pr = float((d.double() * gradproj.proj_vector(n, j, d.shape).double()).sum())
+            assert abs(pr - float(g["delta_proj"][i][j])) < 2e-3 * scale + 1e-12, (n, j, pr, float(g["delta_proj"][i][j]))
+
+
 def test_vendor_forward_equals_oracle():
     """oracle/vendor_forward.py (the reference's op sequence on torch's library ops; bench.py times it on the GPU box as the same-node
     vendor-stack calibration) is the same function as the oracle: tiny32 128x128, shifted and decoder (modulator) blocks included."""
