@@ -189,6 +189,11 @@ int uf_lewin_attn_fwd(const uf_block_params* p, float* x, int ld, int B, int H, 
 /* ---- a10/a11: FFN half (model.py:987): x = x + LeFF(LN2(x)) ; in place. */
 int uf_leff_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
                 uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
+/* ---- a10 with the hidden tensor recomputed on the tile halo (round 5; 2-byte operands, C = 32 or 64): xo = x1 + LeFF(LN2(x1)) in ONE kernel,
+ * OUT OF PLACE (a tile normalises rows of its neighbours) -- h1 = GELU(linear1(LN2 x1)) never exists in HBM (model.py:666-685, :987).
+ * uf_leff_fwd / uf_lewin_block_fwd take this path by themselves where it applies. */
+int uf_leff_halo_fwd(const uf_block_params* p, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C,
+                     uf_dtype dtype, void* stream);
 /* whole block = the two halves */
 int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
                        const float* user_mask, int n_mask, uf_dtype dtype, void* ws,

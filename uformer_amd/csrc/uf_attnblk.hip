@@ -31,6 +31,7 @@ namespace {
 
 struct AttnBlkParams {
     float* x; int ld;
+    float* xo; int ldo;                    // where phase 2 writes the new rows (= x, ld unless the caller wants them out of place)
     const float* gamma; const float* beta; const float* modulator;
     const void* Wqkv; const float* bqkv;   // T[3C][C], f32[3C]
     const float* rpb_tab;                  // f32[heads][15][15] compact Toeplitz rel-pos bias, x reversed: [dy+7][7-dx]
@@ -670,8 +671,13 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         // the rows this wave updates: addresses now, and (2-byte operand types: registers allow it) the residual values and
         // the bias requested BEFORE the k-loop, so that their round trip (L2: the rows were read in phase 0) hides under it
         float* xrow[TMW];
+        float* xorow[TMW];
 #pragma unroll
-        for (int j = 0; j < TMW; ++j) xrow[j] = p.x + (size_t)window_token(geo, (wm * TMW + j) * 16 + fr) * p.ld;
+        for (int j = 0; j < TMW; ++j) {
+            const size_t tok = (size_t)window_token(geo, (wm * TMW + j) * 16 + fr);
+            xrow[j] = p.x + tok * p.ld;
+            xorow[j] = p.xo + tok * p.ldo;
+        }
         constexpr bool PRE = SZ == 2;
         f32x4 res[PRE ? TNW : 1][PRE ? TMW : 1];
         auto proj_requests = [&]() {       // what does not depend on the O tile: weight prologue, residual rows
@@ -715,14 +721,15 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
 #pragma unroll
         for (int j = 0; j < TMW; ++j) {
             float* xr = xrow[j];
+            float* xw = xorow[j];
 #pragma unroll
             for (int i = 0; i < TNW; ++i) {
                 const int n = (wn * TNW + i) * 16 + fg * 4;
                 const f32x4 b = *reinterpret_cast<const f32x4*>(Bq + 3 * C + n);
                 if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b) * dscale;   // the block's new rows stay in registers
                 else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b) * dscale;
-                if (UF_ABL == 5) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]), "v"(xr + n));   // ablation: no row stores
-                else *reinterpret_cast<f32x4*>(xr + n) = acc[i][j];
+                if (UF_ABL == 5) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]), "v"(xw + n));   // ablation: no row stores
+                else *reinterpret_cast<f32x4*>(xw + n) = acc[i][j];
             }
         }
         if constexpr (SZ == 2) {
@@ -820,10 +827,12 @@ bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_
     return C == 32 || C == 64 || C == 128 || C == 256;   // f32: two [64][C] tiles must fit LDS
 }
 
-int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st, const float* drop) {
+int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st, const float* drop,
+                      float* xo, int ldo) {
     AttnBlkParams p{};
     p.drop = drop;
-    p.x = x; p.ld = ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
+    p.x = x; p.ld = ld;
+    p.xo = xo ? xo : x; p.ldo = xo ? ldo : ld; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
     p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
     p.Wp = bp->wproj_fm; p.bp = bp->bproj;
     p.gamma2 = bp->norm2_w; p.beta2 = bp->norm2_b; p.W1 = bp->w1_fm; p.b1 = bp->b1;

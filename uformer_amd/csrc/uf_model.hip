@@ -51,6 +51,16 @@ int check_block_args(const uf_block_params* p, const float* x, int ld, int B, in
 }
 
 // fc1_done (optional): set when the fused kernel also produced the LeFF hidden h1 in w.h1 (whole-block calls only)
+// whole-block calls at the HBM-bound widths (2-byte operands, C = 32 / 64): attn_block writes x1 to the scratch, leff3 recomputes the hidden tensor on its
+// tile halo and writes the block's result back to x -- h1 never exists in HBM (uf_leff3.hip)
+bool halo_block(const uf_block_params* p, const float* user_mask, uf_dtype dtype, int C) {
+    static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr || getenv("UF_NO_FC1_FUSION") != nullptr;
+    return !no_fuse && leff3_supported(dtype, C) && attn_block_supported(p, user_mask, dtype, C, p->heads);
+}
+
+int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask, uf_dtype dtype,
+              const BlockWs& w, hipStream_t st, const float* drop_attn, const float* drop_leff);
+
 int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask,
               uf_dtype dtype, const BlockWs& w, hipStream_t st, bool* fc1_done = nullptr, const float* drop = nullptr) {
     const int M = B * H * W;
@@ -92,6 +102,13 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
               hipStream_t st, bool fc1_done = false, const float* drop = nullptr) {
     const int M = B * H * W;
+    if (!fc1_done && leff3_supported(dtype, C) && getenv("UF_NO_FC1_FUSION") == nullptr) {
+        // the half on its own (uf_leff_fwd): leff3 is out of place, so the rows go to the scratch first
+        float* x1 = reinterpret_cast<float*>(w.h1);
+        UF_REQUIRE(hipMemcpy2DAsync(x1, (size_t)C * 4, x, (size_t)ld * 4, (size_t)C * 4, (size_t)M, hipMemcpyDeviceToDevice, st) == hipSuccess, UF_ERR_LAUNCH,
+                   "leff: copy of the stream rows failed");
+        return launch_leff3(p, x1, C, x, ld, B, H, W, C, dtype, drop, st);
+    }
     // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671) unless the attention kernel did it
     if (!fc1_done) {
         int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1_fm, p->b1, w.h1, M, 4 * C, C, dtype, st);
@@ -102,10 +119,31 @@ int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     return launch_leff2(w.h1, p->wdw9, p->bdw, p->w2_fm, p->b2, x, ld, B, H, W, C, dtype, drop, st);
 }
 
+int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask, uf_dtype dtype,
+              const BlockWs& w, hipStream_t st, const float* drop_attn, const float* drop_leff) {
+    if (halo_block(p, user_mask, dtype, C)) {
+        float* x1 = reinterpret_cast<float*>(w.h1);            // f32 [M][C]: half the bytes of the h1 region it replaces
+        int rc = launch_attn_block(p, x, ld, B, H, W, C, dtype, nullptr, st, drop_attn, x1, C);
+        if (rc) return rc;
+        return launch_leff3(p, x1, C, x, ld, B, H, W, C, dtype, drop_leff, st);
+    }
+    bool fc1_done = false;
+    int rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, st, &fc1_done, drop_attn);
+    if (rc) return rc;
+    return leff_half(p, x, ld, B, H, W, C, dtype, w, st, fc1_done, drop_leff);
+}
+
 }  // namespace
 }  // namespace uf
 
 using namespace uf;
+
+extern "C" int uf_leff_halo_fwd(const uf_block_params* p, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,
+                                void* stream) {
+    UF_REQUIRE(p, UF_ERR_NULL, "uf_leff_halo_fwd: null pointer");
+    UF_REQUIRE(leff3_supported(dtype, C), UF_ERR_UNSUPPORTED, "uf_leff_halo_fwd: bf16 / f16 operands at C = 32 or 64 (got dtype %d, C = %d)", (int)dtype, C);
+    return launch_leff3(p, x1, ld1, xo, ldo, B, H, W, C, dtype, nullptr, (hipStream_t)stream);
+}
 
 extern "C" size_t uf_block_workspace_bytes(int M, int C, uf_dtype dtype) {
     if (M <= 0 || C <= 0) return 0;
@@ -139,10 +177,7 @@ extern "C" int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, in
     BlockWs w;
     rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
     if (rc) return rc;
-    bool fc1_done = false;
-    rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream, &fc1_done);
-    if (rc) return rc;
-    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream, fc1_done);
+    return block_fwd(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* drop_attn,
@@ -152,10 +187,7 @@ extern "C" int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int 
     BlockWs w;
     rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
     if (rc) return rc;
-    bool fc1_done = false;
-    rc = attn_half(p, x, ld, B, H, W, C, nullptr, 0, dtype, w, (hipStream_t)stream, &fc1_done, drop_attn);
-    if (rc) return rc;
-    return leff_half(p, x, ld, B, H, W, C, dtype, w, (hipStream_t)stream, fc1_done, drop_leff);
+    return block_fwd(p, x, ld, B, H, W, C, nullptr, 0, dtype, w, (hipStream_t)stream, drop_attn, drop_leff);
 }
 
 extern "C" int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B,

@@ -502,6 +502,18 @@ def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, 
     return out
 
 
+def leff_halo(bp, x1: Tensor, B: int, H: int, W: int, dtype) -> Tensor:
+    """x1 + LeFF(LN2(x1)) in ONE kernel with the hidden tensor recomputed on the tile halo (uf_leff_halo_fwd; model.py:666-685, :987).
+    bp: _lib.BlockParams (packing.pack_block); x1 f32 (B*H*W, C); 2-byte operand types, C = 32 or 64.  Out of place."""
+    _dev(x1)
+    x1 = _c(x1, torch.float32)
+    Cc = x1.shape[-1]
+    out = torch.empty_like(x1)
+    with torch.cuda.device(x1.device):
+        _lib.check(_lib.load().uf_leff_halo_fwd(bp, _ptr(x1), Cc, _ptr(out), Cc, B, H, W, Cc, uf_dtype(dtype), _stream()), "uf_leff_halo_fwd")
+    return out
+
+
 def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int) -> Tensor:
     """x f32 (B*H*W, C) -> f32 (B*H/2*W/2, 2C).  Downsample.forward model.py:739-746."""
     _dev(x, w_packed, bias)
