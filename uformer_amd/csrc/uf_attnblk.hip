@@ -63,7 +63,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define UF_PRIO_UP() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define UF_PRIO_DN() do { if (UF_SETPRIO) __builtin_amdgcn_s_setprio(0); } while (0)
 #ifndef UF_ABL
-#define UF_ABL 0   // ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads, 4: no h1 stores, 5: no row stores in phase 2); 0 in every shipped build
+#define UF_ABL 0   // ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads, 4: no h1 stores, 5: no row stores in phase 2, 6: no weight-fragment loads in any GEMM phase, 7: no LDS operand-fragment loads, 8: no GELU in phase 3, 9: no softmax arithmetic); 0 in every shipped build
 #endif
 #ifndef UF_LN_ROTATE
 #define UF_LN_ROTATE 0
@@ -104,6 +104,16 @@ template <> struct FragFromAcc<float> {
     static __device__ __forceinline__ void make(Frag<float>& f, f32x4 a, f32x4 b) { f.lo = a; f.hi = b; }
 };
 
+// weight / operand fragment loads of the GEMM phases, with the timing ablations 6 / 7 (registers filled from the lane id instead of memory)
+template <typename T> __device__ __forceinline__ void wfrag_load(Frag<T>& f, const T* p) {
+    if constexpr (UF_ABL == 6 && sizeof(T) == 2) { const unsigned v = 0x3c003c00u ^ (unsigned)(uintptr_t)p; f.v = u32x4{v, v, v, v}; }
+    else load_frag(f, p);
+}
+template <typename T> __device__ __forceinline__ void afrag_load(Frag<T>& f, const T* p) {
+    if constexpr (UF_ABL == 7 && sizeof(T) == 2) { const unsigned v = 0x3c003c00u ^ (unsigned)(uintptr_t)p; f.v = u32x4{v, v, v, v}; }
+    else load_frag(f, p);
+}
+
 template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // balanced pairwise sum, N a power of two
     static_assert((N & (N - 1)) == 0, "power of two");
 #pragma unroll
@@ -129,7 +139,7 @@ struct Fc1Walk {
     int lane;
     __device__ __forceinline__ void wload(int ks, int slot) {
 #pragma unroll
-        for (int i = 0; i < UW; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+        for (int i = 0; i < UW; ++i) wfrag_load(wf[slot][i], wrow[i] + ks * 512);
     }
     __device__ __forceinline__ void unit_prefetch(int u) {
 #pragma unroll
@@ -163,7 +173,7 @@ struct Fc1Walk {
         Frag<T> af[2][4];
         auto aload = [&](int ks, int slot) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(arow + j * 16 * SA + ks * 32 * SZ));
+            for (int j = 0; j < 4; ++j) afrag_load(af[slot][j], reinterpret_cast<const T*>(arow + j * 16 * SA + ks * 32 * SZ));
         };
         aload(0, 0);
         f32x4 bv[UW];   // the unit's bias: requested here, consumed after the k-loop (was an exposed L2 round trip per unit)
@@ -189,7 +199,7 @@ struct Fc1Walk {
 #pragma unroll
             for (int ip = 0; ip < UW; ip += 2) {
                 f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
-                gelu4<T>(va); gelu4<T>(vb);
+                if (UF_ABL != 8) { gelu4<T>(va); gelu4<T>(vb); }
                 const unsigned a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
                 const unsigned c0 = pack2<T>(vb[0], vb[1]), c1 = pack2<T>(vb[2], vb[3]);
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
@@ -266,13 +276,13 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
     Frag<T> wf[WR][LR ? 2 : 6];
     auto wload = [&](int ks, int slot) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) load_frag(wf[slot][i], wrow[i] + ks * 512);
+        for (int i = 0; i < 6; ++i) wfrag_load(wf[slot][i], wrow[i] + ks * 512);
     };
     // LR: step g of the flattened walk = (projection g / KS in the order k, v, q; k-step g % KS): two fragments
     auto wload2 = [&](int g, int slot) {
         const int pj = g / KS, ks = g - pj * KS, base = pj == 0 ? 2 : (pj == 1 ? 4 : 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) load_frag(wf[slot][i], wrow[base + i] + ks * 512);
+        for (int i = 0; i < 2; ++i) wfrag_load(wf[slot][i], wrow[base + i] + ks * 512);
     };
     auto unit_weights = [&](int u) {   // 16-row weight tiles of the unit's head in the fragment-major Wqkv (q tiles h*2+i, k tiles C/16+.., v tiles 2C/16+..) + ring prologue
         const int h = u / (4 / QT);
@@ -399,10 +409,10 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
                 const int pj = g / KS, ks = g - pj * KS;
                 if (pj < 2 || QT == 4) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+                    for (int j = 0; j < 4; ++j) afrag_load(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
                 } else {
 #pragma unroll
-                    for (int j = 0; j < QT; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+                    for (int j = 0; j < QT; ++j) afrag_load(af[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
                 }
             };
             aload2(0, 0);
@@ -495,11 +505,11 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         if constexpr (!HOIST) unit_weights(u);
         auto aload = [&](int ks, int slot) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+            for (int j = 0; j < 4; ++j) afrag_load(af[slot][j], reinterpret_cast<const T*>(Xn + (j * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
             if constexpr (QT < 4) {
 #pragma unroll
                 for (int j = 0; j < QT; ++j)
-                    load_frag(afq[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+                    afrag_load(afq[slot][j], reinterpret_cast<const T*>(Xn + ((q0 + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
             }
         };
         aload(0, 0);
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(s[kt][j][r] - mx);
+                    const float e = UF_ABL == 9 ? s[kt][j][r] - mx : __builtin_amdgcn_exp2f(s[kt][j][r] - mx);
                     s[kt][j][r] = e;
                     sum += e;
                 }
@@ -662,11 +672,11 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         Frag<T> wf[PR][TNW], af[2][TMW];
         auto wload = [&](int ks, int slot) {
 #pragma unroll
-            for (int i = 0; i < TNW; ++i) load_frag(wf[slot][i], Wp + (((size_t)(wn * TNW + i) * KS + ks) * 64 + lane) * 8);
+            for (int i = 0; i < TNW; ++i) wfrag_load(wf[slot][i], Wp + (((size_t)(wn * TNW + i) * KS + ks) * 64 + lane) * 8);
         };
         auto aload = [&](int ks, int slot) {
 #pragma unroll
-            for (int j = 0; j < TMW; ++j) load_frag(af[slot][j], reinterpret_cast<const T*>(Os + ((wm * TMW + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+            for (int j = 0; j < TMW; ++j) afrag_load(af[slot][j], reinterpret_cast<const T*>(Os + ((wm * TMW + j) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
         };
         // the rows this wave updates: addresses now, and (2-byte operand types: registers allow it) the residual values and
         // the bias requested BEFORE the k-loop, so that their round trip (L2: the rows were read in phase 0) hides under it

@@ -57,7 +57,8 @@ int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* 
                  uf_dtype dtype, const float* drop, hipStream_t st);
 
 // the whole LeFF half in one kernel with h1 recomputed on the tile halo (uf_leff3.hip): xo = x1 + DropPath(LeFF(LN2(x1))), out of place
-bool leff3_supported(uf_dtype dtype, int C);
+bool leff3_covers(uf_dtype dtype, int C);      // shapes the kernel is built for
+bool leff3_supported(uf_dtype dtype, int C);   // ... and whole-block calls select it (UF_LEFF3=1; off by default, see uf_leff3.hip)
 int launch_leff3(const uf_block_params* bp, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,
                  const float* drop, hipStream_t st);
 

@@ -53,9 +53,9 @@ __global__ __launch_bounds__(512, WPS) void leff3_kernel(const Leff3Params p) {
     constexpr int WN = (C / 16) < 8 ? (C / 16) : 8, WM = 8 / WN, TNW = (C / 16) / WN, TMW = 4 / WM;   // linear2: wave grid over (out tiles, pixel tiles)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xn = smem;                                        // [HR][SA]
-    char* Hs = Xn + HR * SA;                                // [HT][64] T, swizzled pieces
-    char* At = Hs + HT * PS;                                // [64][SAT]
-    float* Tap = reinterpret_cast<float*>(At + 64 * SAT);   // [10][HID]: 9 tap rows + conv bias
+    char* Hs = Xn + HR * SA;                                // [2][HT][64] T, swizzled pieces
+    char* At = Hs + 2 * HT * PS;                            // [2][64][SAT]
+    float* Tap = reinterpret_cast<float*>(At + 2 * 64 * SAT);   // [10][HID]: 9 tap rows + conv bias
     float* B1s = Tap + 10 * HID;                            // [HID]
     float* Gb = B1s + HID;                                  // [2][C] norm2 weight, bias
 
@@ -111,35 +111,110 @@ __global__ __launch_bounds__(512, WPS) void leff3_kernel(const Leff3Params p) {
     };
     w1_load(0);
 
+    // ---- the schedule: ONE barrier per slot, three independent pieces of work per wave between two barriers -------------------------------
+    // Stream A walks the tiles of this workgroup: slot 0 of a tile = P0 (LN2 of its halo rows -> Xn), slots 1 .. NIT = P1 of chunk 0 .. NIT-1
+    // (h1 chunk -> halo tile Hs[chunk & 1]).  Stream B runs P2 (stencil: Hs[chunk & 1] -> operand tile At[chunk & 1]) of the chunk A produced one
+    // slot earlier, stream C runs P3 (linear2 partial sums from At[chunk & 1]; after the last chunk of a tile: the epilogue) of the chunk B
+    // produced one slot earlier.  The three pieces of a slot touch different buffers, so a wave's LDS round trips, MFMAs and GELU arithmetic of
+    // one piece overlap those of the others, and the pipeline runs across tile borders (the x1 rows of the next tile are requested at the start
+    // of its P0 slot and normalised at its end, behind the stencil and linear2 work of the previous tile).
     const int G = (int)gridDim.x;
+    const int nk = (p.n_tiles - (int)blockIdx.x + G - 1) / G;           // tiles of this workgroup: blockIdx.x + k G
+    constexpr int LPR = C / 4;                                            // P0: lanes per row, one f32x4 each
+    constexpr int RPP = NT / LPR;                                         // rows per pass
+    constexpr int NPASS = (HR + RPP - 1) / RPP;
+    const int sub = tid % LPR;
+    int cb = 0, cy0 = 0, cx0 = 0;                                         // tile of stream A
+    int eb = 0, ey0 = 0, ex0 = 0;                                         // tile whose epilogue is pending
+    bool inimg[4] = {false, false, false, false};
+    int ja = 0, ka = 0;                                                   // stream A: slot within the tile, tile index
+    int itB = -1, itC = -1;                                               // chunk of P2 / P3 in this slot (-1: none)
+    const int NSLOT = nk * (NIT + 1) + 2;
 #pragma unroll 1
-    for (int v = (int)blockIdx.x; v < p.n_tiles; v += G) {
-        const int t = xcd_tile(v, p.n_tiles);
-        const int b = t / (tiles_x * tiles_y);
-        const int tr = t - b * (tiles_x * tiles_y);
-        const int y0 = (tr / tiles_x) * 8, x0 = (tr % tiles_x) * 8;
-        const float* xb = p.x1 + (size_t)b * p.H * p.W * p.ld1;
-        // ---------------- P0: LN2 of the halo rows -> Xn --------------------------------------------------
-        {
-            constexpr int LPR = C / 4;                      // lanes per row, one f32x4 each
-            constexpr int RPP = NT / LPR;                   // rows per pass
-            constexpr int NPASS = (HR + RPP - 1) / RPP;
-            const int sub = tid % LPR;
+    for (int m = 0; m < NSLOT; ++m) {
+        const bool a_p0 = ka < nk && ja == 0;
+        const int itA = (ka < nk && ja > 0) ? ja - 1 : -1;
+        const bool epi = itC == NIT - 1;
+        // ---- requests first: linear2 weight fragments, the epilogue's own x1 rows, the next tile's halo rows ----
+        Frag<T> w2f[2][TNW];
+        if (itC >= 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < TNW; ++i)
+                    load_frag(w2f[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + itC * 2 + ks) * 64 + lane) * 8);
+        }
+        f32x4 xres[TNW][TMW];
+        if (epi) {                                                        // L2: this workgroup's P0 read them
+            const float* xe = p.x1 + (size_t)eb * p.H * p.W * p.ld1;
+#pragma unroll
+            for (int i = 0; i < TNW; ++i)
+#pragma unroll
+                for (int j = 0; j < TMW; ++j) {
+                    const int pm = (wm * TMW + j) * 16 + fr;
+                    xres[i][j] = *reinterpret_cast<const f32x4*>(xe + ((size_t)(ey0 + (pm >> 3)) * p.W + ex0 + (pm & 7)) * p.ld1 + (wn * TNW + i) * 16 + fg * 4);
+                }
+        }
+        auto stream_b = [&]() {
+            // ---------------- stream B, P2: depthwise 3 x 3 + GELU of chunk itB: Hs[itB & 1] -> At[itB & 1] ------------------------
+            if (itB >= 0)
+                mconv_job<T, 1, 2, HID, SAT, 2 * HW_ * PS>(Hs + (itB & 1) * (HT * PS), Tap + itB * 64, At + (itB & 1) * (64 * SAT), gq, pt0, boff, msk, hshift, fr, fg);
+        };
+        auto stream_c = [&]() {
+            // ---------------- stream C, P3: linear2 partial sums of chunk itC from At[itC & 1] (+ epilogue) ------------------------
+            if (itC >= 0) {
+                const char* Ar = At + (itC & 1) * (64 * SAT);
+    #pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    Frag<T> af[TMW];
+    #pragma unroll
+                    for (int j = 0; j < TMW; ++j) load_frag(af[j], reinterpret_cast<const T*>(Ar + ((wm * TMW + j) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
+    #pragma unroll
+                    for (int i = 0; i < TNW; ++i)
+    #pragma unroll
+                        for (int j = 0; j < TMW; ++j) mma16(acc[i][j], w2f[ks][i], af[j]);
+                }
+                if (epi) {
+                    const float dscale = p.drop ? p.drop[eb] : 1.0f;
+                    float* ob = p.xo + (size_t)eb * p.H * p.W * p.ldo;
+    #pragma unroll
+                    for (int i = 0; i < TNW; ++i) {
+                        const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + (wn * TNW + i) * 16 + fg * 4);
+    #pragma unroll
+                        for (int j = 0; j < TMW; ++j) {
+                            const int pm = (wm * TMW + j) * 16 + fr;
+                            *reinterpret_cast<f32x4*>(ob + ((size_t)(ey0 + (pm >> 3)) * p.W + ex0 + (pm & 7)) * p.ldo + (wn * TNW + i) * 16 + fg * 4) =
+                                xres[i][j] + (acc[i][j] + b2) * dscale;
+                            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+                }
+            }
+        };
+        if (a_p0) {
             f32x4 vv[NPASS];
+            const int t = xcd_tile((int)blockIdx.x + ka * G, p.n_tiles);
+            cb = t / (tiles_x * tiles_y);
+            const int tr = t - cb * (tiles_x * tiles_y);
+            cy0 = (tr / tiles_x) * 8; cx0 = (tr % tiles_x) * 8;
+            const float* xb = p.x1 + (size_t)cb * p.H * p.W * p.ld1;
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + tid / LPR;
                 const int hy = row / HW_, hx = row - hy * HW_;
-                const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+                const int iy = cy0 + hy - 1, ix = cx0 + hx - 1;
                 const bool ok = row < HT && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 vv[ps] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * p.W + ix) * p.ld1 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            stream_b();
+            stream_c();
+        // ---------------- stream A, P0: LN2 of the halo rows requested above -> Xn ------------------------------------------------
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
                 const int row = ps * RPP + tid / LPR;
-                float s = (vv[ps][0] + vv[ps][1]) + (vv[ps][2] + vv[ps][3]);
-                s = allreduce<RedSum, LPR>(s);
-                const float mean = s * (1.0f / C);
+                float sm = (vv[ps][0] + vv[ps][1]) + (vv[ps][2] + vv[ps][3]);
+                sm = allreduce<RedSum, LPR>(sm);
+                const float mean = sm * (1.0f / C);
                 const f32x4 d = vv[ps] - mean;
                 float sq = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
                 sq = allreduce<RedSum, LPR>(sq);
@@ -147,107 +222,64 @@ __global__ __launch_bounds__(512, WPS) void leff3_kernel(const Leff3Params p) {
                 const f32x4 gm = *reinterpret_cast<const f32x4*>(Gb + sub * 4), bt = *reinterpret_cast<const f32x4*>(Gb + C + sub * 4);
                 if (row < HR) store4(reinterpret_cast<T*>(Xn + row * SA) + sub * 4, d * rstd * gm + bt);
             }
-        }
-        // which of this lane's halo pixels lie inside the image (h1 is ZERO outside: the convolution's padding, model.py:659)
-        bool inimg[4];
+            // which of this lane's halo pixels of the P1 role lie inside the image
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int hp = (rt0 + j) * 16 + fr;
-            const int hy = hp / HW_, hx = hp - hy * HW_;
-            const int iy = y0 + hy - 1, ix = x0 + hx - 1;
-            inimg[j] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            for (int j = 0; j < 4; ++j) {
+                const int hp = (rt0 + j) * 16 + fr;
+                const int hy = hp / HW_, hx = hp - hy * HW_;
+                const int iy = cy0 + hy - 1, ix = cx0 + hx - 1;
+                inimg[j] = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            }
+        // ---------------- stream A, P1: h1 chunk itA on the halo -> Hs[itA & 1] --------------------------------------------------
+        } else if (itA >= 0) {
+            char* Hw = Hs + (itA & 1) * (HT * PS);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(B1s + itA * 64 + ct * 16 + fg * 4);
+#pragma unroll
+            for (int jh = 0; jh < 4; jh += 2) {                           // two row tiles at a time (registers)
+                if (rt0 + jh < 7) {
+                    f32x4 a1[2];
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ++ks) {
+                        Frag<T> af[2];
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)                        // (row tile 7 of the second half does not exist: its rows are the padding of the last)
+                            load_frag(af[j], reinterpret_cast<const T*>(Xn + ((rt0 + jh + j < 7 ? rt0 + jh + j : 6) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) mma16(a1[j], w1f[ks], af[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if (hoff[jh + j] >= 0) {
+                            f32x4 h = a1[j] + bv;
+                            gelu4<T>(h);
+                            u32x2 o = {pack2<T>(h[0], h[1]), pack2<T>(h[2], h[3])};
+                            if (!inimg[jh + j]) o = u32x2{0u, 0u};        // the convolution pads h1 with zeros (model.py:659)
+                            *reinterpret_cast<u32x2*>(Hw + hoff[jh + j]) = o;
+                        }
+                    }
+                }
+            }
+            // the next chunk's (or the next tile's first) weight fragments: in flight until the next slot
+            w1_load(itA + 1 < NIT ? itA + 1 : 0);
+            if (itA == NIT - 1) { eb = cb; ey0 = cy0; ex0 = cx0; }       // this tile's epilogue runs two slots from now
+            stream_b();
+            stream_c();
+        } else {
+            stream_b();
+            stream_c();
         }
         lds_barrier();
-#pragma unroll 1
-        for (int it = 0; it < NIT; ++it) {
-            // ---------------- P1: h1 chunk on the halo ----------------------------------------------------
-            {
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(B1s + it * 64 + ct * 16 + fg * 4);
-#pragma unroll
-                for (int jh = 0; jh < 4; jh += 2) {         // two row tiles at a time (registers)
-                    if (rt0 + jh < 7) {
-                        f32x4 a1[2];
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) a1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int ks = 0; ks < KS1; ++ks) {
-                            Frag<T> af[2];
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)      // (row tile 7 of the second half does not exist: its rows are the padding of the last)
-                                load_frag(af[j], reinterpret_cast<const T*>(Xn + ((rt0 + jh + j < 7 ? rt0 + jh + j : 6) * 16 + fr) * SA + (ks * 32 + fg * 8) * SZ));
-#pragma unroll
-                            for (int j = 0; j < 2; ++j) mma16(a1[j], w1f[ks], af[j]);
-                        }
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            if (hoff[jh + j] >= 0) {
-                                f32x4 h = a1[j] + bv;
-                                gelu4<T>(h);
-                                u32x2 o = {pack2<T>(h[0], h[1]), pack2<T>(h[2], h[3])};
-                                if (!inimg[jh + j]) o = u32x2{0u, 0u};
-                                *reinterpret_cast<u32x2*>(Hs + hoff[jh + j]) = o;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                // next chunk's (or the next tile's first) weight fragments: in flight under the stencil and linear2 phases
-                w1_load(it + 1 < NIT ? it + 1 : 0);
-            }
-            lds_barrier();
-            // ---------------- P2: depthwise 3 x 3 + GELU -> operand tile -----------------------------------
-            Frag<T> w2f[2][TNW];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int i = 0; i < TNW; ++i)
-                    load_frag(w2f[ks][i], W2 + (((size_t)(wn * TNW + i) * (HID / 32) + it * 2 + ks) * 64 + lane) * 8);
-            f32x4 xres[TNW][TMW];
-            if (it == NIT - 1) {                            // the tile's own x1 rows for the epilogue (L2: P0 read them)
-#pragma unroll
-                for (int i = 0; i < TNW; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMW; ++j) {
-                        const int pm = (wm * TMW + j) * 16 + fr;
-                        xres[i][j] = *reinterpret_cast<const f32x4*>(xb + ((size_t)(y0 + (pm >> 3)) * p.W + x0 + (pm & 7)) * p.ld1 + (wn * TNW + i) * 16 + fg * 4);
-                    }
-            }
-            mconv_job<T, 1, 2, HID, SAT, 2 * HW_ * PS>(Hs, Tap + it * 64, At, gq, pt0, boff, msk, hshift, fr, fg);
-            lds_barrier();
-            // ---------------- P3: linear2 partial sums ------------------------------------------------------
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                Frag<T> af[TMW];
-#pragma unroll
-                for (int j = 0; j < TMW; ++j) load_frag(af[j], reinterpret_cast<const T*>(At + ((wm * TMW + j) * 16 + fr) * SAT + (ks * 32 + fg * 8) * SZ));
-#pragma unroll
-                for (int i = 0; i < TNW; ++i)
-#pragma unroll
-                    for (int j = 0; j < TMW; ++j) mma16(acc[i][j], w2f[ks][i], af[j]);
-            }
-            if (it == NIT - 1) {
-                const float dscale = p.drop ? p.drop[b] : 1.0f;
-                float* ob = p.xo + (size_t)b * p.H * p.W * p.ldo;
-#pragma unroll
-                for (int i = 0; i < TNW; ++i) {
-                    const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.b2 + (wn * TNW + i) * 16 + fg * 4);
-#pragma unroll
-                    for (int j = 0; j < TMW; ++j) {
-                        const int pm = (wm * TMW + j) * 16 + fr;
-                        *reinterpret_cast<f32x4*>(ob + ((size_t)(y0 + (pm >> 3)) * p.W + x0 + (pm & 7)) * p.ldo + (wn * TNW + i) * 16 + fg * 4) =
-                            xres[i][j] + (acc[i][j] + b2) * dscale;
-                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                }
-            }
-        }
+        itC = itB; itB = itA;
+        if (ka < nk) { if (++ja > NIT) { ja = 0; ++ka; } }
     }
 }
 
 template <typename T, int C>
 int launch_c(const Leff3Params& p, hipStream_t st) {
     constexpr int HID = 4 * C;
-    constexpr int smem = 112 * (C * 2 + 16) + 100 * 128 + 64 * (64 * 2 + 16) + 10 * HID * 4 + HID * 4 + 2 * C * 4;
+    constexpr int smem = 112 * (C * 2 + 16) + 2 * 100 * 128 + 2 * 64 * (64 * 2 + 16) + 10 * HID * 4 + HID * 4 + 2 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     // two 8-wave workgroups per CU: the kernel needs 96 (C = 32) / 121 (C = 64) registers, i.e. 4 waves per SIMD; a third workgroup (<= 80 registers)
     // spills 15 / 48 of them (UF_LEFF3_WPS=6 builds that variant for A/B runs)
@@ -276,10 +308,16 @@ int launch_c(const Leff3Params& p, hipStream_t st) {
 
 }  // namespace
 
+bool leff3_covers(uf_dtype dtype, int C) { return dtype_half(dtype) && (C == 32 || C == 64); }
+
+// Whether whole-block calls take this kernel.  OFF by default: measured on MI355X (profiles/r05_run1_ab.txt, r05_run2_ab.txt) the pair
+// attn_block (without its fc1 phase) + leff3 is SLOWER than attn_block(+fc1) + leff2 at every width it covers -- dec3 (1 M tokens, C = 64)
+// 196 + 538 us against 366 + 269, enc1 52 + 139 against 90 + 71, enc0 (C = 32) 97 + 263 against 175 + 133 -- although it moves half the
+// bytes: these stages are bound by VALU issue (GELU, LayerNorm, conversions), not by HBM, and the halo costs 1.75 x the linear1 / GELU / LN2
+// work.  UF_LEFF3=1 selects it (A/B runs); uf_leff_halo_fwd reaches it directly.
 bool leff3_supported(uf_dtype dtype, int C) {
-    static const char* e = getenv("UF_LEFF3");              // A/B: UF_LEFF3=0 keeps the attn_block(+fc1) -> leff2 pair everywhere
-    if (e && e[0] == '0') return false;
-    return dtype_half(dtype) && (C == 32 || C == 64);
+    static const char* e = getenv("UF_LEFF3");
+    return e && e[0] == '1' && leff3_covers(dtype, C);
 }
 
 int launch_leff3(const uf_block_params* bp, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,

@@ -141,7 +141,7 @@ using namespace uf;
 extern "C" int uf_leff_halo_fwd(const uf_block_params* p, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,
                                 void* stream) {
     UF_REQUIRE(p, UF_ERR_NULL, "uf_leff_halo_fwd: null pointer");
-    UF_REQUIRE(leff3_supported(dtype, C), UF_ERR_UNSUPPORTED, "uf_leff_halo_fwd: bf16 / f16 operands at C = 32 or 64 (got dtype %d, C = %d)", (int)dtype, C);
+    UF_REQUIRE(leff3_covers(dtype, C), UF_ERR_UNSUPPORTED, "uf_leff_halo_fwd: bf16 / f16 operands at C = 32 or 64 (got dtype %d, C = %d)", (int)dtype, C);
     return launch_leff3(p, x1, ld1, xo, ldo, B, H, W, C, dtype, nullptr, (hipStream_t)stream);
 }
 
