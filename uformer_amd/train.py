@@ -472,8 +472,15 @@ class UformerTape:
         t = stage_fwd(4, t)
         for k in range(4):
             self.up_in.append(t)
-            up = ops.upsample(t, packing.pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], T), sd[f"upsample_{k}.deconv.0.bias"], B, res[4 + k], res[4 + k])
-            t = stage_fwd(5 + k, torch.cat([up, self.skips[3 - k]], 1))           # model.py:1288
+            # torch.cat([up, skip], -1) (model.py:1288) without the concatenation pass: Upsample scatters straight into the first half of the
+            # decoder stage's input rows (the inference path's concat buffer, uf_upsample_fwd with ld_o = 2 Cs), the skip is copied into the second
+            skip = self.skips[3 - k]
+            Cs = skip.shape[1]
+            cat = torch.empty((skip.shape[0], 2 * Cs), dtype=torch.float32, device=skip.device)
+            ops.upsample(t, packing.pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], T), sd[f"upsample_{k}.deconv.0.bias"], B, res[4 + k], res[4 + k],
+                         out=cat, ld_o=2 * Cs)
+            cat[:, Cs:].copy_(skip)
+            t = stage_fwd(5 + k, cat)
         self.head_in = t
         return ops.output_proj(t, packing.pack_output_proj(sd["output_proj.proj.0.weight"]), sd["output_proj.proj.0.bias"], B, H, W,
                                img if cfg.dd_in == 3 else None)
