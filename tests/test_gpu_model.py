@@ -334,6 +334,24 @@ def test_forward_captured_in_a_hip_graph(B):
             assert torch.equal(static_y, want[i]), (B, i, (static_y - want[i]).abs().max().item())
 
 
+def test_graphed_forward_helper_replays_bit_identically():
+    """uformer_amd.infer.GraphedForward (small-batch serving: capture once, copy the batch into the static input, replay): equal to the eager
+    forward bit for bit on fresh inputs, a clear error for another shape, and ``recapture()`` picks up changed weights."""
+    from uformer_amd import infer
+    cfg = spec.arch_config("tiny32", img_size=128)
+    m = build(cfg, spec.synth_state_dict(cfg, 31), torch.bfloat16)
+    xs = [spec.synth_input(2, 128, 128, 60 + i).cuda() for i in range(3)]
+    with torch.no_grad():
+        gf = infer.GraphedForward(m, xs[0])
+        for x in xs:
+            assert torch.equal(gf(x), m(x))
+        with pytest.raises(ValueError):
+            gf(spec.synth_input(1, 128, 128, 1).cuda())
+        m.output_proj.proj[0].bias.data.add_(0.125)
+        gf.recapture()
+        assert torch.equal(gf(xs[1]), m(xs[1]))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_forward_backward_captured_in_a_hip_graph(dtype):
     """Forward + backward of a training step inside ONE HIP graph (torch.cuda.CUDAGraph around the module call and loss.backward()): the

@@ -393,7 +393,7 @@ def test_lewin_block_golden(golden, dtype, tag):
 
 def test_leff2_and_attn_block_variants_bit_identical():
     """The launch variants that are chosen by shape (and therefore by batch size) must agree bit for bit, or a batch-16 forward would not equal 16
-    single forwards: leff2 with 8 producer waves / consumer stencil jobs / the persistent tile walk, attn_block in its low-register forms.  The
+    single forwards: leff2 with 8 producer waves / the persistent tile walk, attn_block in its low-register forms.  The
     switches are read once per process, so every variant runs in a child process and returns hashes of its outputs on the same inputs."""
     import os
     import subprocess
@@ -423,7 +423,7 @@ print("HASHES " + " ".join(out))
 """ % root
     res = {}
     for tag, env in (("default", {}), ("leff2 8 producers", {"UF_LEFF2_VARIANT": "p"}), ("leff2 never 8 producers", {"UF_LEFF2_VARIANT": "n"}),
-                     ("leff2 consumer stencil jobs", {"UF_LEFF2_VARIANT": "c"}), ("leff2 one tile per workgroup", {"UF_LEFF2_PERSIST": "0"}),
+                     ("leff2 one tile per workgroup", {"UF_LEFF2_PERSIST": "0"}),
                      ("leff2 tile walk everywhere", {"UF_LEFF2_PERSIST": "1"}), ("attn_block first form", {"UF_ATTN_LR": "0"}),
                      ("attn_block low-register form", {"UF_ATTN_LR": "1"}), ("attn_block low-register code, first bounds", {"UF_ATTN_LR": "2"})):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))

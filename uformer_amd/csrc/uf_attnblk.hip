@@ -65,6 +65,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 #ifndef UF_ABL
 #define UF_ABL 0   // ablations for profiling (1: no x loads, 2: no LN math, 3: no modulator loads, 4: no h1 stores, 5: no row stores in phase 2, 6: no weight-fragment loads in any GEMM phase, 7: no LDS operand-fragment loads, 8: no GELU in phase 3, 9: no softmax arithmetic); 0 in every shipped build
 #endif
+// UF_NT (experiment, bit mask): non-temporal hints on the activation streams so that they do not evict the block's weights (4 MB at C = 512 = one
+// XCD's whole L2) -- 1: h1 stores, 2: the new x rows of phase 2, 4: the x loads of phase 0
+#ifndef UF_NT
+#define UF_NT 0
+#endif
 #ifndef UF_LN_ROTATE
 #define UF_LN_ROTATE 0
 #endif
@@ -206,6 +211,7 @@ struct Fc1Walk {
                 const u32x2_t s1 = __builtin_amdgcn_permlane16_swap(a1, c1, false, false);
                 const int n = nbase + (ip + (fg & 1)) * 16 + (fg >> 1) * 8;
                 if (UF_ABL == 4) asm volatile("" :: "v"(s0[0]), "v"(s1[0]), "v"(s0[1]), "v"(s1[1]), "v"(h1 + rowoff[j] + n));   // ablation: no h1 stores
+                else if (UF_NT & 1) __builtin_nontemporal_store(u32x4{s0[0], s1[0], s0[1], s1[1]}, reinterpret_cast<u32x4*>(h1 + rowoff[j] + n));
                 else *reinterpret_cast<u32x4*>(h1 + rowoff[j] + n) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
         }
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
 #pragma unroll
                 for (int i = 0; i < V4; ++i) {
                     if (UF_ABL == 1) v[u][i] = f32x4{(float)src, (float)i, (float)sub, 1.0f};   // ablation: no x loads
+                    else if (UF_NT & 4) v[u][i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4));
                     else v[u][i] = *reinterpret_cast<const f32x4*>(p.x + (size_t)src * p.ld + (i * LPR + sub) * 4);
                 }
             }
@@ -739,6 +746,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
                 if constexpr (PRE) acc[i][j] = res[i][j] + (acc[i][j] + b) * dscale;   // the block's new rows stay in registers
                 else acc[i][j] = *reinterpret_cast<const f32x4*>(xr + n) + (acc[i][j] + b) * dscale;
                 if (UF_ABL == 5) asm volatile("" :: "v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]), "v"(xw + n));   // ablation: no row stores
+                else if (UF_NT & 2) __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(xw + n));
                 else *reinterpret_cast<f32x4*>(xw + n) = acc[i][j];
             }
         }

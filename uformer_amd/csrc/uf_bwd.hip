@@ -245,14 +245,11 @@ __global__ __launch_bounds__(256) void column_sum2_kernel(const float* __restric
     } else column_sum_block(p2, P2, s2, o2, n2, blockIdx.x - nb1);
 }
 static inline void launch_column_sum2(hipStream_t st, const float* p1, int P1, size_t s1, float* o1, int n1, const float* p2, int P2, size_t s2, float* o2, int n2) {
-    static const bool narrow = getenv("UF_COLSUM_V1") != nullptr;                    // A/B: the one-column-per-thread form everywhere
-    const bool vec = !narrow && n1 % 4 == 0 && s1 % 4 == 0 && ((uintptr_t)p1 % 16) == 0 && ((uintptr_t)o1 % 16) == 0;
+    const bool vec = n1 % 4 == 0 && s1 % 4 == 0 && ((uintptr_t)p1 % 16) == 0 && ((uintptr_t)o1 % 16) == 0;
     // p-lanes so that about 256 K threads share the work (a thread of the one-lane form walks all P partials: 4-8 dependent round trips
     // of 8 loads on 256 workgroups); the summation order depends only on (n, P)
-    static const int lanes_env = getenv("UF_COLSUM_LANES") ? atoi(getenv("UF_COLSUM_LANES")) : 0;             // A/B: 1 = the first rule (1 / 4 lanes)
     int wide1 = 0;
-    if (vec && lanes_env == 1) wide1 = n1 >= (1 << 18) ? 1 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0);
-    else if (vec) wide1 = n1 >= (1 << 20) ? 1 : (n1 >= (1 << 18) ? (P1 >= 8 ? 4 : 1) : (n1 >= (1 << 14) && P1 >= 32 ? 16 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0)));
+    if (vec) wide1 = n1 >= (1 << 20) ? 1 : (n1 >= (1 << 18) ? (P1 >= 8 ? 4 : 1) : (n1 >= (1 << 14) && P1 >= 32 ? 16 : (n1 >= (1 << 15) && P1 >= 8 ? 4 : 0)));
     const int nb1 = wide1 ? (n1 / 4 + 256 / wide1 - 1) / (256 / wide1) : (n1 + 31) / 32, nb2 = (n2 + 31) / 32;
     hipLaunchKernelGGL(column_sum2_kernel, dim3(nb1 + nb2), dim3(256), 0, st, p1, P1, s1, o1, n1, nb1, p2, P2, s2, o2, n2, wide1);
 }
@@ -268,8 +265,8 @@ constexpr int LN_BWD_MAX_BLOCKS = 512;
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int DWB_R = 4;
 // workgroups of dwconv3x3_wgrad_kernel: 176 VGPRs = 2 workgroups per CU resident -> 512 fills the chip once (256 left every SIMD with
-// ONE wave of a memory-bound kernel); UF_DWWGRAD_BLOCKS overrides for A/B runs
-static int dw_wgrad_blocks() { static const int v = getenv("UF_DWWGRAD_BLOCKS") ? atoi(getenv("UF_DWWGRAD_BLOCKS")) : 0; return v > 0 ? v : 512; }
+// ONE wave of a memory-bound kernel)
+static int dw_wgrad_blocks() { return 512; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_wgrad_kernel(const T* __restrict__ h, const T* __restrict__ dc, float* __restrict__ partial,
@@ -1844,14 +1841,13 @@ extern "C" int uf_dwconv3x3_wgrad(const void* h, const void* dc, float* dw9, flo
 }
 
 // geometry of the fused depthwise backward for C channels: 4 channels per thread (8-byte loads for the 2-byte types; with 8 the
-// accumulators spill), channel groups per workgroup (a power of two dividing C / 4, at most 32), workgroups (UF_DWBWD_BLOCKS,
-// default 1024 = four per CU, rounded up to whole channel-block rounds)
+// accumulators spill), channel groups per workgroup (a power of two dividing C / 4, at most 32), workgroups (1024 = four per CU,
+// rounded up to whole channel-block rounds)
 static void dw_bwd_geometry(int C, int* cg_log2, int* blocks) {
-    static const int target = getenv("UF_DWBWD_BLOCKS") ? atoi(getenv("UF_DWBWD_BLOCKS")) : 0;
     const int cv = C / 4;
     int lg = 0;
     while (lg < 5 && cv % (2 << lg) == 0) ++lg;
-    const int cb = cv >> lg, want = target > 0 ? target : 1024;
+    const int cb = cv >> lg, want = 1024;
     *cg_log2 = lg; *blocks = (want + cb - 1) / cb * cb;
 }
 
@@ -1885,9 +1881,8 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
     dw_bwd_geometry(C, &lg, &blocks);
     const int cb = (C / 4) >> lg;
     hipStream_t st = (hipStream_t)stream;
-    static const bool walk = !(getenv("UF_DWCONV_WALK") && atoi(getenv("UF_DWCONV_WALK")) == 0);   // 0: one pixel column per thread (A/B)
     // the walking form for the 2-byte types (with f32 operands its 72 column registers on top of the erf-form GELU spill)
-    const int seg = (walk && dtype_half(dtype) && W % 8 == 0) ? (W % 16 == 0 ? 16 : 8) : 0;
+    const int seg = (dtype_half(dtype) && W % 8 == 0) ? (W % 16 == 0 ? 16 : 8) : 0;
     for (int b0 = 0; b0 < B; b0 += chunkB) {
         const int Bc = B - b0 < chunkB ? B - b0 : chunkB;
         const size_t off = (size_t)b0 * per_img;
@@ -1915,14 +1910,13 @@ extern "C" int uf_dwconv3x3_bwd(const void* dc, const float* w9_flipped, const v
     return UF_OK;
 }
 
-static bool wgrad_v2() { static const bool off = getenv("UF_WGRAD_V1") != nullptr; return !off; }   // UF_WGRAD_V1=1: first version (A/B, tests)
+static bool wgrad_v2() { return true; }   // 2-byte operand types: the 128 x 128-tile kernels (the first version serves f32)
 static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     const int T = (dtype_half(dtype) && wgrad_v2()) ? 128 : 64;
     const int tiles = ((N + T - 1) / T) * ((K + T - 1) / T), steps = (M + 31) / 32;
     // workgroups per launch to aim for: every chunk costs one N x K f32 partial written and read again by the ordered sum, so no more
-    // chunks than it takes to fill the chip (128-wide tiles: 2 workgroups per CU resident; UF_WGRAD_TARGET overrides, for A/B runs)
-    static const int target_env = getenv("UF_WGRAD_TARGET") ? atoi(getenv("UF_WGRAD_TARGET")) : 0;
-    const int target = target_env > 0 ? target_env : (T == 128 ? 512 : 2048);   // 512 vs 1024 vs 2048 measured: 148.8 / 151.0 / 151.1 ms per training step
+    // chunks than it takes to fill the chip (128-wide tiles: 2 workgroups per CU resident)
+    const int target = T == 128 ? 512 : 2048;   // 512 vs 1024 vs 2048 measured: 148.8 / 151.0 / 151.1 ms per training step
     int S = target / tiles;
     if (S > steps) S = steps;
     if (S > 256) S = 256;
@@ -1941,9 +1935,8 @@ static bool wgrad4_shape(int M, int N, int K) {
     return M >= 65536 && (long long)N * K >= 196608;
 }
 static int wgrad4_chunks(int M, int N, int K) {
-    static const int target_env = getenv("UF_WGRAD4_TARGET") ? atoi(getenv("UF_WGRAD4_TARGET")) : 0;
     const int tiles = (N / 256) * (K / 256), steps = (M + WG4_TOK - 1) / WG4_TOK;
-    int S = (target_env > 0 ? target_env : 256) / tiles;     // one workgroup per CU (128 KiB of LDS each)
+    int S = 256 / tiles;     // one workgroup per CU (128 KiB of LDS each)
     if (S > steps / 4) S = steps / 4;                         // at least four stages per chunk
     if (S > 256) S = 256;
     return S < 1 ? 1 : S;
@@ -1980,11 +1973,10 @@ extern "C" int uf_linear_wgrad(const void* dY, int ldy, const void* X, int ldx, 
     if (timing_enabled()) snprintf(name, sizeof(name), "linear_wgrad_%s %dx%dx%d", dtype_name(dtype), M, N, K);
     {
         ScopedTimer tm(name, 2.0 * M * N * K, (double)M * (N + K) * dtype_size(dtype) + 4.0 * N * K, st);
-        static const int xcd_map = !(getenv("UF_WGRAD_XCD") && atoi(getenv("UF_WGRAD_XCD")) == 0);          // 0: chunk-major order (A/B)
+        constexpr int xcd_map = 1;          // XCD-aware chunk order (profiles/r03_wgrad_xcd.txt)
         const dim3 grid2((unsigned)(grid.x * (xcd_map ? (S + 7) / 8 * 8 : S)));
-        // third version (LDS-DMA staging, 64-token steps) where both operands are addressable with 32-bit byte offsets; UF_WGRAD_DMA=0: second version
-        const char* e3 = getenv("UF_WGRAD_DMA");
-        const bool v3 = v2 && !(e3 && e3[0] == '0') && M >= 256 && ((long long)M + 64) * ldy * 2 < 0xffffff00LL && ((long long)M + 64) * ldx * 2 < 0xffffff00LL;
+        // third version (LDS-DMA staging, 64-token steps) where both operands are addressable with 32-bit byte offsets, else the second version
+        const bool v3 = v2 && M >= 256 && ((long long)M + 64) * ldy * 2 < 0xffffff00LL && ((long long)M + 64) * ldx * 2 < 0xffffff00LL;
         const dim3 grid3((unsigned)(grid.x * ((S + 7) / 8 * 8)));
         const dim3 grid4((unsigned)((N / 256) * (K / 256) * ((S + 7) / 8 * 8)));
         if (v4 && dtype == UF_BF16) hipLaunchKernelGGL(linear_wgrad4_kernel<bf16>, grid4, dim3(512), 0, st, (const bf16*)dY, ldy, (const bf16*)X, ldx, ws_w, ws_b, M, N, K, S);
@@ -2047,9 +2039,8 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
                                bias_dense, mask, n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows,    \
                                heads, H, W, shift);                                                                                                   \
         }
-        // second version (accumulators chained into the operands, nothing stored transposed) for the 2-byte types; UF_ATTN_BWD_V1=1: first version
-        const char* ev1 = getenv("UF_ATTN_BWD_V1");
-        const bool v2 = dtype_half(dtype) && !(ev1 && ev1[0] == '1') && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)dO % 16) == 0;
+        // second version (accumulators chained into the operands, nothing stored transposed) for the 2-byte types (the first version serves f32)
+        const bool v2 = dtype_half(dtype) && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)dO % 16) == 0;
 #define UF_ATTN_BWD2(TT, HDV)                                                                                                                       \
         if (mask) hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV, true>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
                            n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);                            \

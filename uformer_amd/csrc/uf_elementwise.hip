@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void input_proj_kernel(const float* __restrict
 //
 // What was wrong.  Under the model's two half-batch streams the first builds of this kernel returned wrong pixels for the side-stream images in 2 of 10 ...
 // 10 of 10 forwards (never alone, never on one stream).  Not a stream-ordering problem: the kernel ALONE on a side stream is wrong whenever a kernel with
-// MFMA waves (the GEMM, leff2, attn_block) runs on the main stream, and exact beside ATen kernels or another stem (scripts/r04_dbg8.py,
+// MFMA waves (the GEMM, leff2, attn_block) runs on the main stream, and exact beside ATen kernels or another stem (scripts/history/r04_dbg8.py,
 // profiles/r04_run17.txt); the wrong elements are columns 48..63 of a 64-pixel tile = lanes 48-63, even channels only, and only the pixels whose products
 // use element 1 of an LDS vector read.  hipcc had compiled `acc[q] += v[q + kx] * wv` into `v_pk_fma_f32 acc, wv, v[2j:2j+1], acc op_sel:[0,1,0]` (the pixel
 // value = the HIGH half of a register pair, selected for both results).  That instruction form returns a wrong LOW result in lanes 48-63 about once in 1e7
@@ -752,9 +752,8 @@ extern "C" int uf_layernorm_fwd(const float* x, int ld_x, const float* gamma, co
 namespace {
 template <typename T, int ACT>
 void launch_dwconv(const void* x, const float* w9, const float* bias, void* out, void* aux, int B, int H, int W, int C, hipStream_t st) {
-    if constexpr (ACT != 3) {     // the walking form: W a multiple of 8, tensor under 4 GiB (32-bit byte offsets); UF_DWCONV_WALK=0 turns it off (A/B)
-        static const bool walk = !(getenv("UF_DWCONV_WALK") && atoi(getenv("UF_DWCONV_WALK")) == 0);
-        if (walk && W % 8 == 0 && C % 4 == 0 && (unsigned long long)B * H * W * C * sizeof(T) < 0xffffffffULL) {
+    if constexpr (ACT != 3) {     // the walking form: W a multiple of 8, tensor under 4 GiB (32-bit byte offsets)
+        if (W % 8 == 0 && C % 4 == 0 && (unsigned long long)B * H * W * C * sizeof(T) < 0xffffffffULL) {
             const int seg = W % 16 == 0 ? 16 : 8;
             const long long n = (long long)B * (H / DW_R) * (W / seg) * (C / 4);
             const dim3 grid((unsigned)((n + 255) / 256));
@@ -827,9 +826,8 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
     UF_REQUIRE(B > 0 && Cin > 0 && H > 0 && W > 0 && E % 4 == 0 && ld_o >= E && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_input_proj_fwd: bad shape");
     UF_REQUIRE((long long)B * Cin * H * W < 0x7fffffffLL && (long long)Cin * 9 * E < 0x7fffffffLL, UF_ERR_SHAPE, "uf_input_proj_fwd: image too large for 32-bit indexing");
     UF_REQUIRE(H <= 65535 && B <= 65535, UF_ERR_SHAPE, "uf_input_proj_fwd: H=%d B=%d exceed the launch grid", H, B);
-    // pixels per thread: 4 (81 loads per 432 FMAs) or 8 (117 per 864); UF_INPUT_PROJ_PX=4|8 overrides
-    static const int px_env = getenv("UF_INPUT_PROJ_PX") ? atoi(getenv("UF_INPUT_PROJ_PX")) : 0;
-    const int px = px_env == 8 || px_env == 4 ? px_env : IP_PX_DEFAULT;
+    // pixels per thread of the first form: 4 (81 loads per 432 FMAs) or 8 (117 per 864)
+    const int px = IP_PX_DEFAULT;
     const unsigned nx = (unsigned)((W + px - 1) / px) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
     // The LDS-staged second form (input_proj2_kernel: 107 -> 44 us at 16 x 256 x 256, bit-identical to the first form) is the default since the
@@ -842,9 +840,6 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
         const int dyn = (UF_IP2_DBG & 32) ? 16384 : 0;
         if (E == 32) hipLaunchKernelGGL(input_proj2_kernel<8>, g32, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
         else hipLaunchKernelGGL(input_proj2_kernel<4>, g16, dim3(256), dyn, (hipStream_t)stream, img, w27, bias, out, ld_o, B, H, W);
-        // diagnosis of the stale-row reads (see above): UF_IP2_FENCE=1 puts an empty kernel between this one and its consumer on the same stream
-        static const int fence = getenv("UF_IP2_FENCE") ? atoi(getenv("UF_IP2_FENCE")) : 0;
-        if (fence == 1) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
         return check_launch("input_proj");
     }
     if (px == 8) hipLaunchKernelGGL(input_proj_kernel<8>, dim3((nx + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, img, w27, bias, out, ld_o, B, Cin, H, W, E);

@@ -468,10 +468,9 @@ int launch_kern(const GemmParams& p, hipStream_t stream) {
     // K within ONE tile (K <= 64 for the 2-byte types: every projection of the 32- and 64-channel stages, the ones with the most tokens):
     // the second LDS buffer is never touched, and without it 3-4 workgroups fit a CU instead of 2 -- these launches are streams of
     // short load -> MFMA -> store chains, bound by how many of them are in flight.  (The staged epilogue of the 2-byte types fits one
-    // buffer; the f32 one and the f32 staging of the residual stores do not.)  UF_GEMM_LDS2=1 keeps both buffers, for A/B runs.
-    static const bool lds2 = getenv("UF_GEMM_LDS2") != nullptr;
+    // buffer; the f32 one and the f32 staging of the residual stores do not.)
     constexpr int BKE = 8 * (16 / (int)sizeof(T));
-    const int smem = (!DMA && sizeof(T) == 2 && EP != E_RES && EP != E_RES_WINREV && p.K <= BKE && !lds2) ? smem2 / 2 : smem2;   // (the f32 staging of the residual stores needs both)
+    const int smem = (!DMA && sizeof(T) == 2 && EP != E_RES && EP != E_RES_WINREV && p.K <= BKE) ? smem2 / 2 : smem2;   // (the f32 staging of the residual stores needs both)
     const int m_tiles = (p.M + BM - 1) / BM, n_tiles = (p.N + BN - 1) / BN;
     dim3 grid((unsigned)(((m_tiles + 7) / 8) * 8 * n_tiles));
     char name[96] = "";

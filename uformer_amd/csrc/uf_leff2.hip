@@ -430,11 +430,8 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
 // Shape -> variant.  bf16: C <= 128: 8-wave workgroups small enough (51 KiB, <= 80 registers) for three per CU; C = 256: two per
 // CU (3-deep DMA ring, 128 registers); C = 512: 4 stencil + 8 MFMA waves, one workgroup per CU (the consumers' accumulators and
 // their W2 prefetch need 168 registers).  f32 (parity mode): one configuration per width.
-// UF_LEFF2_VARIANT=a selects the alternatives measured against these (A/B switch: 8 stencil waves working on 128-channel
-// intervals where a CU gets a single workgroup; two workgroups per CU at C = 128).
 template <typename T, int C>
 int launch_c(const Leff2Params& p, hipStream_t st) {
-    static const bool alt = getenv("UF_LEFF2_VARIANT") && getenv("UF_LEFF2_VARIANT")[0] == 'a';
     const int tiles = p.B * (p.H / 8) * (p.W / 8);
     if constexpr (sizeof(T) == 2 && UF_MCONV != 0 && C >= 32) {
         // 8 producer waves per 64-channel group (two pixel tiles each) where the grid is at most one round of workgroups: a producer wave
@@ -444,27 +441,18 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
         // workgroups cost residency (dec1 0.631 -> 0.739, C <= 64 +4...9 %): profiles/r04_run2.txt.  UF_LEFF2_VARIANT=p forces it, =n never.
         static const char* ev = getenv("UF_LEFF2_VARIANT");
         const bool force = ev && ev[0] == 'p', never = ev && ev[0] == 'n';
-        // UF_LEFF2_VARIANT=c: consumer waves take a quarter (C <= 256) / half (C = 512) of the stencil jobs (template parameter CP)
-        const bool cj = ev ? ev[0] == 'c' : UF_LEFF2_CP_DEFAULT;
-        if (cj) {
-            if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6, 4, 1>(p, st);
-            else if constexpr (C == 256) return launch_v<T, C, 1, 4, 3, 4, 4, 1>(p, st);
-            else return launch_v<T, C, 1, 8, 3, 3, 4, 2>(p, st);
-        }
+        // (Stencil jobs on the consumer waves -- template parameter CP -- measured -8 % in round 4, profiles/r04_run7.txt, and are not instantiated.)
         if constexpr (C == 128) { if (!never && (force || tiles <= 1024)) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
         else if constexpr (C == 256) { if (!never && (force || tiles <= 256)) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st); }
         else if constexpr (C == 512) { if (force) return launch_v<T, C, 1, 8, 4, 4, 8>(p, st); }
         else { if (force) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
     }
     if constexpr (sizeof(T) == 2) {
-        if constexpr (C <= 64) return launch_v<T, C, 1, 4, 2, 6>(p, st);
-        else if constexpr (C == 128) return alt ? launch_v<T, C, 1, 4, 3, 4>(p, st) : launch_v<T, C, 1, 4, 2, 6>(p, st);
-        else if constexpr (C == 256) {
-            if (alt && tiles <= 256) return launch_v<T, C, 2, 8, 3, 4>(p, st);
-            return launch_v<T, C, 1, 4, 3, 4>(p, st);
-        } else return alt ? launch_v<T, C, 2, 8, 3, 4>(p, st) : launch_v<T, C, 1, 8, 3, 3>(p, st);
+        if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6>(p, st);
+        else if constexpr (C == 256) return launch_v<T, C, 1, 4, 3, 4>(p, st);
+        else return launch_v<T, C, 1, 8, 3, 3>(p, st);
     } else {
-        (void)tiles; (void)alt;
+        (void)tiles;
         if constexpr (C <= 256) return launch_v<T, C, 1, 4, 2, 2>(p, st);
         else return launch_v<T, C, 1, 4, 2, 2>(p, st);
     }

@@ -357,9 +357,8 @@ int launch_bm(const LnGemmParams& p, hipStream_t st) {
     // 128-row blocks when the operand tile fits 64 KiB of LDS and there are enough blocks to fill
     // 256 CUs twice over; otherwise 64-row blocks.
     constexpr bool fits128 = 128 * (C * (int)sizeof(T) + 16) <= 68 * 1024;
-    static const int bm_env = getenv("UF_LNGEMM_BM") ? atoi(getenv("UF_LNGEMM_BM")) : 0;   // tuning override
     if constexpr (fits128) {
-        if ((p.M >= 128 * 512 && bm_env != 64) || bm_env == 128) return launch_one<T, C, 128, EP>(p, st);
+        if (p.M >= 128 * 512) return launch_one<T, C, 128, EP>(p, st);
     }
     return launch_one<T, C, 64, EP>(p, st);
 }

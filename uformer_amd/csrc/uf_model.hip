@@ -54,8 +54,7 @@ int check_block_args(const uf_block_params* p, const float* x, int ld, int B, in
 // whole-block calls at the HBM-bound widths (2-byte operands, C = 32 / 64): attn_block writes x1 to the scratch, leff3 recomputes the hidden tensor on its
 // tile halo and writes the block's result back to x -- h1 never exists in HBM (uf_leff3.hip)
 bool halo_block(const uf_block_params* p, const float* user_mask, uf_dtype dtype, int C) {
-    static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr || getenv("UF_NO_FC1_FUSION") != nullptr;
-    return !no_fuse && leff3_supported(dtype, C) && attn_block_supported(p, user_mask, dtype, C, p->heads);
+    return leff3_supported(dtype, C) && attn_block_supported(p, user_mask, dtype, C, p->heads);
 }
 
 int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask, uf_dtype dtype,
@@ -68,14 +67,10 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
     const int heads = p->heads, hd = C / heads;
     // one fused kernel per window when the shape is covered (head_dim 32): LN1, q/k/v, attention, proj,
     // window_reverse and the residual never leave the CU                       (model.py:951-986)
-    static const bool no_fuse = getenv("UF_NO_ATTN_FUSION") != nullptr;   // A/B switch for tests and profiling
-    static const bool no_fc1 = getenv("UF_NO_FC1_FUSION") != nullptr;
-    // UF_UNFUSE_BELOW=n (experiment): stages with fewer than n windows take the 3-kernel path, whose GEMMs tile over the whole chip where
-    // the fused kernel has one workgroup per window (64 windows at the bottleneck of a batch of 16)
-    static const int unfuse_below = getenv("UF_UNFUSE_BELOW") ? atoi(getenv("UF_UNFUSE_BELOW")) : 0;
-    const bool small = !drop && unfuse_below > 0 && M / 64 < unfuse_below;
-    if (!no_fuse && !small && attn_block_supported(p, user_mask, dtype, C, heads)) {
-        const bool with_fc1 = fc1_done && !no_fc1 && dtype_half(dtype) && C >= 32;
+    // (Stages with fewer windows than CUs -- 4 ... 64 at small batches -- stay on the fused kernel too: the 3-kernel path, whose GEMMs tile over the
+    // whole chip, measured slower at every batch size from 1 to 16: profiles/r03_unfuse.txt, profiles/r05_run5_unfuse.txt.)
+    if (attn_block_supported(p, user_mask, dtype, C, heads)) {
+        const bool with_fc1 = fc1_done && dtype_half(dtype) && C >= 32;
         if (fc1_done) *fc1_done = with_fc1;
         return launch_attn_block(p, x, ld, B, H, W, C, dtype, with_fc1 ? w.h1 : nullptr, st, drop);
     }
@@ -102,7 +97,7 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
               hipStream_t st, bool fc1_done = false, const float* drop = nullptr) {
     const int M = B * H * W;
-    if (!fc1_done && leff3_supported(dtype, C) && getenv("UF_NO_FC1_FUSION") == nullptr) {
+    if (!fc1_done && leff3_supported(dtype, C)) {
         // the half on its own (uf_leff_fwd): leff3 is out of place, so the rows go to the scratch first
         float* x1 = reinterpret_cast<float*>(w.h1);
         UF_REQUIRE(hipMemcpy2DAsync(x1, (size_t)C * 4, x, (size_t)ld * 4, (size_t)C * 4, (size_t)M, hipMemcpyDeviceToDevice, st) == hipSuccess, UF_ERR_LAUNCH,
@@ -291,26 +286,12 @@ int forward_one_stream(const uf_model_desc* d, const float* img, float* out, int
         ld = 2 * pl.C[s];
     };
     const uf_block_params* blk = d->blocks;
-    // Image chunks (UF_CHUNK_MB = working-set target in MiB, 0 = off): a block's two kernels run chunk by chunk -- attn_block(chunk) then
-    // leff2(chunk) -- so that the 4C-wide hidden tensor h1 one writes and the other reads (half of a block's HBM bytes at C <= 128) and the
-    // chunk's stream rows stay inside the 256 MiB Infinity Cache instead of making a round trip through HBM; every chunk reuses the same
-    // scratch.  Images never interact inside a block, so the results are bit-identical to the whole-batch launches.
-    static const long long chunk_mb = getenv("UF_CHUNK_MB") ? atoll(getenv("UF_CHUNK_MB")) : 0;
+    // (Running a block's two kernels image chunk by image chunk, so that h1 stays inside the 256 MiB Infinity Cache between them, measured neutral
+    // in round 3 -- profiles/r03_chunk_ab.txt -- and is gone.)
     auto run_stage = [&](int s, float* x, int ld) -> int {
-        const size_t per_img = (size_t)pl.res[s] * pl.res[s] * pl.C[s] * (4 * dtype_size(dtype) + 2 * sizeof(float));   // h1 + the stream rows in and out
-        int cb = B;
-        if (chunk_mb > 0) {
-            const long long fit = (long long)((size_t)chunk_mb * 1024 * 1024 / per_img);
-            cb = fit < 1 ? 1 : (fit > B ? B : (int)fit);
-            if ((long long)cb * (pl.res[s] / 8) * (pl.res[s] / 8) < 1024) cb = B;     // never starve the chip: a chunk keeps >= 1024 workgroups
-        }
         for (int i = 0; i < d->depths[s]; ++i, ++blk) {
-            for (int b0 = 0; b0 < B; b0 += cb) {
-                const int bn = B - b0 < cb ? B - b0 : cb;
-                int r = uf_lewin_block_fwd(blk, x + (size_t)b0 * pl.res[s] * pl.res[s] * ld, ld, bn, pl.res[s], pl.res[s], pl.C[s], nullptr, 0, dtype, bws,
-                                           pl.blk_bytes, st);
-                if (r) return r;
-            }
+            int r = uf_lewin_block_fwd(blk, x, ld, B, pl.res[s], pl.res[s], pl.C[s], nullptr, 0, dtype, bws, pl.blk_bytes, st);
+            if (r) return r;
         }
         return UF_OK;
     };

@@ -16,28 +16,6 @@ template <> __device__ __forceinline__ void store8_t<float>(float* p, const floa
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
 }
 
-// thread = 8 consecutive k of one row n.  K % 32 == 0, N % 16 == 0.
-template <typename T>
-__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ src0, int n0, const float* __restrict__ src1, int N, int K,
-                                                          T* __restrict__ plain, T* __restrict__ transposed, T* __restrict__ fm) {
-    const int kc = K / 8;
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)N * kc) return;
-    const int n = (int)(idx / kc), k = (int)(idx % kc) * 8;
-    const float* row = n < n0 ? src0 + (size_t)n * K : src1 + (size_t)(n - n0) * K;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(row + k), b = *reinterpret_cast<const f32x4*>(row + k + 4);
-    const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    if (plain) store8_t<T>(plain + (size_t)n * K + k, f);
-    if (fm) {
-        const int KS = K / 32;
-        store8_t<T>(fm + ((((size_t)(n >> 4) * KS + (k >> 5)) * 64 + ((k & 31) >> 3) * 16 + (n & 15)) << 3), f);
-    }
-    if (transposed) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) store1(transposed + (size_t)(k + e) * N + n, f[e]);
-    }
-}
-
 // the four matrices AND the vectors / tables of a block in ONE launch: workgroup ranges [0, e[0]), [e[0], e[1]), ... own one job each (the
 // five launches were 3-7 us kernels, 200 per training step: 1.3 ms of a 76 ms step in profiles/r04_run13.txt)
 struct MatJob { const float *src0, *src1; int n0, N, K; void *plain, *tr, *fm; };
@@ -69,26 +47,6 @@ struct SmallPack {
     int C, heads;
 };
 
-__global__ __launch_bounds__(256) void pack_small_kernel(const SmallPack p) {
-    const int C = p.C, C4 = 4 * C;
-    const int n_b = 3 * C, n_w = 9 * C4, n_d = p.heads * 4096, n_t = p.heads * 225;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_b + 2 * n_w + n_d + n_t; i += gridDim.x * 256) {
-        int j = i;
-        if (j < n_b) { p.bqkv[j] = j < C ? p.qb[j] : p.kvb[j - C]; continue; }
-        j -= n_b;
-        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9[j] = p.dw[c * 9 + t]; continue; }                 // (4C,1,3,3) -> (9,4C)
-        j -= n_w;
-        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9_flip[j] = p.dw[c * 9 + 8 - t]; continue; }
-        j -= n_w;
-        if (j < n_d) { const int h = j >> 12, qk = j & 4095; p.dense[j] = p.table[(size_t)p.index[qk] * p.heads + h]; continue; }
-        j -= n_d;
-        {   // tab[h][dy+7][7-dx] = table[(dy+7)*15 + (dx+7)][h]   (the reference's relative_position_index, model.py:471-481)
-            const int h = j / 225, r = j - h * 225, a = r / 15, b = r - a * 15;
-            p.tab[j] = p.table[(size_t)(a * 15 + (14 - b)) * p.heads + h];
-        }
-    }
-}
-
 __device__ __forceinline__ void pack_small_items(const SmallPack& p, int first, int stride) {
     const int C = p.C, C4 = 4 * C;
     const int n_b = 3 * C, n_w = 9 * C4, n_d = p.heads * 4096, n_t = p.heads * 225;
@@ -102,6 +60,7 @@ __device__ __forceinline__ void pack_small_items(const SmallPack& p, int first, 
         j -= n_w;
         if (j < n_d) { const int h = j >> 12, qk = j & 4095; p.dense[j] = p.table[(size_t)p.index[qk] * p.heads + h]; continue; }
         j -= n_d;
+        // tab[h][dy+7][7-dx] = table[(dy+7)*15 + (dx+7)][h]   (the reference's relative_position_index, model.py:471-481)
         { const int h = j / 225, r = j - h * 225, a = r / 15, b = r - a * 15; p.tab[j] = p.table[(size_t)(a * 15 + (14 - b)) * p.heads + h]; }
     }
 }
@@ -135,12 +94,6 @@ PackPlan plan_pack(int C, int heads, uf_dtype dtype) {
     return p;
 }
 
-template <typename T>
-void launch_pack_linear(const float* s0, int n0, const float* s1, int N, int K, void* plain, void* tr, void* fm, hipStream_t st) {
-    const long long n = (long long)N * (K / 8);
-    hipLaunchKernelGGL(pack_linear_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s0, n0, s1, N, K, (T*)plain, (T*)tr, (T*)fm);
-}
-
 }  // namespace
 }  // namespace uf
 
@@ -167,8 +120,7 @@ extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int he
     SmallPack sp{raw->to_q_b, raw->to_kv_b, raw->dw_w, raw->rpb_table, (const long long*)raw->rpb_index,
                  (float*)at(pl.bqkv), (float*)at(pl.w9), (float*)at(pl.w9_flip), (float*)at(pl.dense), (float*)at(pl.tab), C, heads};
     const int n_small = 3 * C + 72 * C + heads * (4096 + 225);
-    static const bool one_launch = !(getenv("UF_PACK_LAUNCHES") && atoi(getenv("UF_PACK_LAUNCHES")) == 5);     // 5: the five-launch form (A/B runs, tests)
-    if (one_launch) {
+    {   // one launch for the four weight matrices and the small tensors (round 4; the five-launch form it replaced is gone)
         BlockPackJobs j;
         j.m[0] = MatJob{raw->to_q_w, raw->to_kv_w, C, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm)};
         j.m[1] = MatJob{raw->proj_w, nullptr, C, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm)};
@@ -182,14 +134,6 @@ extern "C" int uf_pack_block_train(const uf_block_raw_params* raw, int C, int he
         j.sp = sp;
         j.n_small_blocks = (n_small + 255) / 256;
         UF_DISPATCH(dtype, TT, hipLaunchKernelGGL(pack_block_kernel<TT>, dim3((unsigned)(end + j.n_small_blocks)), dim3(256), 0, st, j));
-    } else {
-        UF_DISPATCH(dtype, TT, {
-            launch_pack_linear<TT>(raw->to_q_w, C, raw->to_kv_w, 3 * C, C, at(pl.wqkv), at(pl.wqkv_t), at(pl.wqkv_fm), st);
-            launch_pack_linear<TT>(raw->proj_w, C, nullptr, C, C, at(pl.wp), at(pl.wp_t), at(pl.wp_fm), st);
-            launch_pack_linear<TT>(raw->lin1_w, 4 * C, nullptr, 4 * C, C, at(pl.w1), at(pl.w1_t), at(pl.w1_fm), st);
-            launch_pack_linear<TT>(raw->lin2_w, C, nullptr, C, 4 * C, at(pl.w2), at(pl.w2_t), at(pl.w2_fm), st);
-        });
-        hipLaunchKernelGGL(pack_small_kernel, dim3((n_small + 255) / 256), dim3(256), 0, st, sp);
     }
     if (int rc = check_launch("pack_block_train")) return rc;
     if (fwd) {

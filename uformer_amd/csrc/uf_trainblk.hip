@@ -149,16 +149,10 @@ int recompute_attn(const uf_block_train_params* p, const BlockPlan& pl, const fl
 int recompute_leff(const uf_block_train_params* p, const BlockPlan& pl, const float* x1, int B, int H, int W, int C, uf_dtype dtype, void* st) {
     const int M = B * H * W;
     UF_TRY(uf_layernorm_fwd(x1, C, p->norm2_w, p->norm2_b, nullptr, pl.z, B, H, W, C, 0, 0, dtype, st));
-    // linear1 keeps only its pre-activation; the stencil activates it as it loads it (UF_DW_GELU_IN=0, or the two-kernel depthwise backward that
-    // reads h1: both tensors written, the stencil reads the activation)
-    static const bool gelu_in = !(getenv("UF_DW_GELU_IN") && atoi(getenv("UF_DW_GELU_IN")) == 0) && !(getenv("UF_DW_BWD_FUSED") && atoi(getenv("UF_DW_BWD_FUSED")) == 0);
-    if (gelu_in) {
-        UF_TRY(uf_linear_fwd(pl.z, p->w1, p->b1, pl.a1, M, 4 * C, C, 0, dtype, st));
-        UF_TRY(uf_dwconv3x3_gelu_in_pre_gelu_fwd(pl.a1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
-    } else {
-        UF_TRY(uf_linear_pre_gelu_fwd(pl.z, p->w1, p->b1, pl.a1, pl.h1, M, 4 * C, C, dtype, st));
-        UF_TRY(uf_dwconv3x3_pre_gelu_fwd(pl.h1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
-    }
+    // linear1 keeps only its pre-activation; the stencil activates it as it loads it (the fused depthwise backward recomputes the
+    // activation from it)
+    UF_TRY(uf_linear_fwd(pl.z, p->w1, p->b1, pl.a1, M, 4 * C, C, 0, dtype, st));
+    UF_TRY(uf_dwconv3x3_gelu_in_pre_gelu_fwd(pl.a1, p->wdw9, p->bdw, pl.c, pl.g2, B, H, W, 4 * C, dtype, st));
     return UF_OK;
 }
 
@@ -174,18 +168,10 @@ int backward_leff(const uf_block_train_params* p, const BlockPlan& pl, const flo
     UF_TRY(qs.fork());
     UF_TRY(uf_linear_wgrad(pl.tA, C, pl.g2, C4, g->w2, g->b2, M, C, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_mul_dgelu(pl.tA, p->w2_t, pl.zero, pl.c, pl.dc, M, C4, C, dtype, st));                               // dc = (dyT W2) GELU'(c)
-    static const bool dw_fused = !(getenv("UF_DW_BWD_FUSED") && atoi(getenv("UF_DW_BWD_FUSED")) == 0);
-    if (dw_fused) {   // da1 and the tap / bias gradients in one pass over dc (h1 recomputed from a1); the taps come out on the main queue
-        UF_TRY(uf_dwconv3x3_bwd(pl.dc, p->wdw9_flip, pl.a1, pl.da1, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch, pl.scratch_bytes, st));
-        hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)pl.dw9, g->wdw, C4);
-        UF_TRY(check_launch("taps_to_param"));
-    } else {
-        UF_TRY(qs.fork());
-        UF_TRY(uf_dwconv3x3_wgrad(pl.h1, pl.dc, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
-        hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)sw, (const float*)pl.dw9, g->wdw, C4);
-        UF_TRY(check_launch("taps_to_param"));
-        UF_TRY(uf_dwconv3x3_mul_dgelu(pl.dc, p->wdw9_flip, pl.a1, pl.da1, B, H, W, C4, dtype, st));                        // da1
-    }
+    // da1 and the tap / bias gradients in one pass over dc (h1 recomputed from a1); the taps come out on the main queue
+    UF_TRY(uf_dwconv3x3_bwd(pl.dc, p->wdw9_flip, pl.a1, pl.da1, pl.dw9, g->bdw, B, H, W, C4, dtype, pl.scratch, pl.scratch_bytes, st));
+    hipLaunchKernelGGL(taps_to_param_kernel, dim3((9 * C4 + 255) / 256), dim3(256), 0, (hipStream_t)st, (const float*)pl.dw9, g->wdw, C4);
+    UF_TRY(check_launch("taps_to_param"));
     UF_TRY(qs.fork());
     UF_TRY(uf_linear_wgrad(pl.da1, C4, pl.z, C, g->w1, g->b1, M, C4, C, dtype, pl.scratch_w, pl.scratch_w_bytes, sw));
     UF_TRY(uf_linear_fwd(pl.da1, p->w1_t, pl.zero, pl.tE, M, C, C4, 0, dtype, st));                                        // dz
@@ -256,7 +242,7 @@ extern "C" int uf_lewin_block_bwd(const uf_block_train_params* p, const float* x
         UF_TRY(zero_bias(pl, C, stream));
         UF_TRY(recompute_attn(p, pl, x, drop_attn, true, B, H, W, C, dtype, stream));
         UF_TRY(recompute_leff(p, pl, pl.x1, B, H, W, C, dtype, stream));
-        static const bool fuse_fork = !(getenv("UF_LN_BWD_CAST") && atoi(getenv("UF_LN_BWD_CAST")) == 0);
+        constexpr bool fuse_fork = true;
         if (fuse_fork) {   // dx1 = LN2-path gradient + dy -> fB and T(dx1 * drop_attn) in window order -> dyw, from the LN2 backward kernel itself
             UF_TRY(backward_leff(p, pl, pl.x1, dy, drop_leff, g, B, H, W, C, dtype, qs, pl.dyw, drop_attn));
         } else {

@@ -105,3 +105,43 @@ def restore_tiled(model, img: Tensor, tile: int = 768, min_overlap: int = 128, c
             wsum[:, :, y:y + th, x:x + tw] += wgt
     res = acc / wsum
     return torch.clamp(res, 0, 1) if clamp else res
+
+
+class GraphedForward:
+    """Small-batch serving: ``Uformer.forward`` for ONE input shape captured in a HIP graph and replayed.
+
+    The reference's evaluation scripts restore one image per call (test/test_sidd.py:101-107: batch 1), and a forward is ~90 kernel launches:
+    at batch 1-4 the launches and the gaps between them are a large part of the step.  ``GraphedForward(model, example)`` runs the forward once
+    eagerly on a private stream (packs the weights, allocates that stream's workspace), captures a second run into a ``torch.cuda.CUDAGraph``
+    (the library's own side-stream fork / join is followed by the capture, tests/test_gpu_model.py::test_forward_captured_in_a_hip_graph) and
+    ``__call__`` copies the new batch into the static input buffer and replays -- bit-identical to the eager forward.  The returned tensor
+    is the graph's static output: clone it if it must survive the next call.  Weights are read at replay time (the graph holds
+    pointers into the packed-weight buffers): call ``recapture()`` after the model's parameters changed."""
+
+    def __init__(self, model, example: Tensor):
+        if not example.is_cuda:
+            raise ValueError("GraphedForward needs a CUDA example input")
+        self.model = model
+        self._x = example.detach().clone()
+        self._stream = torch.cuda.Stream(device=example.device)
+        self.recapture()
+
+    @torch.no_grad()
+    def recapture(self) -> None:
+        st = self._stream
+        st.wait_stream(torch.cuda.current_stream(self._x.device))
+        with torch.cuda.stream(st):
+            self.model(self._x)                               # warm-up on the capture stream: packed weights + this stream's workspace
+        torch.cuda.current_stream(self._x.device).wait_stream(st)
+        torch.cuda.synchronize(self._x.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, stream=st):
+            self._y = self.model(self._x)
+
+    @torch.no_grad()
+    def __call__(self, x: Tensor) -> Tensor:
+        if x.shape != self._x.shape or x.dtype != self._x.dtype or x.device != self._x.device:
+            raise ValueError(f"GraphedForward was captured for {tuple(self._x.shape)} {self._x.dtype} on {self._x.device}, got {tuple(x.shape)} {x.dtype} on {x.device}")
+        self._x.copy_(x)
+        self._graph.replay()
+        return self._y

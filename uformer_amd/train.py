@@ -197,8 +197,9 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
 
 
 _SIDE_STREAMS: Dict[str, list] = {}
-_GELU_IN = os.environ.get("UF_DW_GELU_IN", "1") != "0"            # 0: linear1 writes pre-activation AND activation, the stencil reads the latter (A/B runs)
-_DW_BWD_FUSED = os.environ.get("UF_DW_BWD_FUSED", "1") != "0"      # 0: the two-kernel form (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad), for A/B runs
+# module attributes, not environment switches (round 5): the shipped forms; the alternatives stay reachable for tests / A-B runs by setting the attribute
+_GELU_IN = True            # False: linear1 writes pre-activation AND activation, the stencil reads the latter
+_DW_BWD_FUSED = True       # False: the two-kernel depthwise backward (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad)
 
 
 class _Side:
@@ -232,7 +233,7 @@ class _Side:
                 self.cur.wait_stream(side)
 
 
-_FUSE_FORK = os.environ.get("UF_LN_BWD_CAST", "1") != "0"          # 0: separate grad_fork passes (A/B runs, tests)
+_FUSE_FORK = True          # False: separate grad_fork passes (tests set the attribute)
 _NO_CAST = object()
 
 
