@@ -542,7 +542,7 @@ def main():
         # HBM bytes per launch of that kernel from the PMC passes of scripts/official_run.sh -- only if they were collected on
         # exactly these kernel sources (stamp); a number from an older build would silently go stale, so it is dropped instead
         tfiles = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")), reverse=True)       # newest round first
-        note = "null: no PMC passes of this build (scripts/official_run_r04.sh collects them)"
+        note = "null: no PMC passes of this build (scripts/official_run_r05.sh collects them)"
         for tf in tfiles:
             try:
                 with open(tf) as f:

@@ -13,8 +13,12 @@ import torch
 from uformer_amd import _lib, model
 
 lib = _lib.load()
-tag = sys.argv[1] if len(sys.argv) > 1 else "default"
 shapes = [(16, 64, 256, 8, "dec1"), (16, 32, 512, 16, "dec0"), (16, 32, 256, 8, "enc3"), (16, 16, 512, 16, "bott"), (32, 32, 512, 16, "dec0@B32"), (16, 64, 128, 4, "enc2")]
+if "--all" in sys.argv:            # every stage shape of Uformer-B 256x256 at batch 16
+    sys.argv.remove("--all")
+    shapes = [(16, 256, 32, 1, "enc0"), (16, 128, 64, 2, "enc1"), (16, 64, 128, 4, "enc2"), (16, 32, 256, 8, "enc3"), (16, 16, 512, 16, "bott"),
+              (16, 32, 512, 16, "dec0"), (16, 64, 256, 8, "dec1"), (16, 128, 128, 4, "dec2"), (16, 256, 64, 2, "dec3")]
+tag = sys.argv[1] if len(sys.argv) > 1 else "default"
 out = {}
 for (B, H, C, heads, name) in shapes:
     torch.manual_seed(C)
@@ -40,4 +44,7 @@ for (B, H, C, heads, name) in shapes:
     a = [v for k, v in d.items() if k.startswith("attn_block")]
     l = [v for k, v in d.items() if k.startswith("leff")]
     out[name] = (a[0] if a else 0.0, l[0] if l else 0.0)
+depth = {"enc0": 1, "enc1": 2, "enc2": 8, "enc3": 8, "bott": 2, "dec0": 8, "dec1": 8, "dec2": 2, "dec3": 1}
+if all(n in depth for n in out):
+    print(f"{tag:<22} all 40 blocks of a forward: {sum(depth[n] * (a + l) for n, (a, l) in out.items()) / 1e3:.3f} ms of kernel time")
 print(f"{tag:<22}" + "  ".join(f"{n}: attn {a:6.1f} leff {l:6.1f}" for n, (a, l) in out.items()), flush=True)

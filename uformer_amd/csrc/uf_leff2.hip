@@ -430,6 +430,24 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
 // Shape -> variant.  bf16: C <= 128: 8-wave workgroups small enough (51 KiB, <= 80 registers) for three per CU; C = 256: two per
 // CU (3-deep DMA ring, 128 registers); C = 512: 4 stencil + 8 MFMA waves, one workgroup per CU (the consumers' accumulators and
 // their W2 prefetch need 168 registers).  f32 (parity mode): one configuration per width.
+// depth of the halo-tile DMA ring (NBUF) per width (compile-time knobs of the round-5 experiment).  Hypothesis: a workgroup has NBUF - 1 slots in
+// flight while it convolves one, so an interval cannot be shorter than (loaded HBM latency) / (NBUF - 1) -- C = 512 with 3 slots: 63 us / 32 intervals
+// = 2 us.  Measured (profiles/r05_run8_ring.txt): C = 512 with 3 / 5 / 8 slots 66.2 / 66.3 / 67.0 us, C = 256 (enc3 form) 3 / 6 slots 30.3 / 31.5,
+// dec1 on one 16-wave workgroup per CU with 5 / 8 slots 100.9 / 96.2 against 83.3 for two 8-wave workgroups with 3: the ring is NOT the limit;
+// the role stamps (profiles/r05_run9_leff2_stamps.txt) show the consumers' interval (2.2 K cycles of work for 0.5 K of MFMA at C = 512) as the
+// longer chain.
+#ifndef UF_NB512
+#define UF_NB512 3
+#endif
+#ifndef UF_NB256
+#define UF_NB256 3
+#endif
+#ifndef UF_NB256E
+#define UF_NB256E 3
+#endif
+#ifndef UF_L256_BIG
+#define UF_L256_BIG 0   // 1: dec1-sized grids on 8 + 8 waves, one workgroup per CU, NBUF = UF_NB256E
+#endif
 template <typename T, int C>
 int launch_c(const Leff2Params& p, hipStream_t st) {
     const int tiles = p.B * (p.H / 8) * (p.W / 8);
@@ -443,14 +461,14 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
         const bool force = ev && ev[0] == 'p', never = ev && ev[0] == 'n';
         // (Stencil jobs on the consumer waves -- template parameter CP -- measured -8 % in round 4, profiles/r04_run7.txt, and are not instantiated.)
         if constexpr (C == 128) { if (!never && (force || tiles <= 1024)) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
-        else if constexpr (C == 256) { if (!never && (force || tiles <= 256)) return launch_v<T, C, 1, 8, 3, 4, 8>(p, st); }
+        else if constexpr (C == 256) { if (!never && (force || tiles <= 256 || UF_L256_BIG)) return launch_v<T, C, 1, 8, UF_NB256E, 4, 8>(p, st); }
         else if constexpr (C == 512) { if (force) return launch_v<T, C, 1, 8, 4, 4, 8>(p, st); }
         else { if (force) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
     }
     if constexpr (sizeof(T) == 2) {
         if constexpr (C <= 128) return launch_v<T, C, 1, 4, 2, 6>(p, st);
-        else if constexpr (C == 256) return launch_v<T, C, 1, 4, 3, 4>(p, st);
-        else return launch_v<T, C, 1, 8, 3, 3>(p, st);
+        else if constexpr (C == 256) return launch_v<T, C, 1, 4, UF_NB256, 4>(p, st);
+        else return launch_v<T, C, 1, 8, UF_NB512, 3>(p, st);
     } else {
         (void)tiles;
         if constexpr (C <= 256) return launch_v<T, C, 1, 4, 2, 2>(p, st);
