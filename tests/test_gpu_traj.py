@@ -16,10 +16,12 @@ import gradproj  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-# loss-curve tolerance (relative, every step) and weight-change tolerance (projections, relative to delta_max * sqrt(numel)); f32 = the VERDICT's
-# 1e-5, the 2-byte types its 2 % -- the measured values are written to gpurun_out/parity_traj_<dtype>.json
-LOSS_RTOL = {torch.float32: 1e-5, torch.float16: 2e-2, torch.bfloat16: 2e-2}
-DELTA_TOL = {torch.float32: 2e-2, torch.float16: 0.3, torch.bfloat16: 0.6}
+# loss-curve tolerance (relative, every step) and weight-change tolerance (projections, relative to delta_max * sqrt(numel)).  VERDICT r04 asked for
+# 1e-5 (f32) and 2 % (2-byte types) on the loss curve; the gates are set at 2-4 x what the kernels measure on MI355X (profiles/r05_parity_traj_*.json:
+# loss f32 8.8e-8 / f16 5.0e-5 / bf16 3.3e-4; weight-change projections 5.6e-4 / 9.3e-2 / 3.9e-1 -- Adam normalises every gradient element to O(lr), so
+# operand rounding shows in the small-gradient elements of a tensor; final weights f32 1.3e-6)
+LOSS_RTOL = {torch.float32: 1e-5, torch.float16: 2e-4, torch.bfloat16: 1e-3}
+DELTA_TOL = {torch.float32: 2e-3, torch.float16: 0.2, torch.bfloat16: 0.6}
 TAG = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 
 
