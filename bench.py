@@ -307,12 +307,14 @@ def train_mode(args, cfg, sd, dev, ud, dtype_name):
            "loss_is_finite": bool(torch.isfinite(state["loss"]).item()),
            "loss": float(state["loss"].detach()), "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30,
            "mfma_frac_whole_step": v * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[dtype_name],
-           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep",
+           "gradient_exchange": "none (1 GPU)" if world == 1 else
+           f"{'RCCL' if torch.distributed.get_backend() == 'nccl' else torch.distributed.get_backend()} all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep",
            "global_batch": world * B, "exchange_buckets": (len(sink.buckets) if sink is not None else 0),
            "exchange_bytes_per_step": (sum(int(f_.numel()) * 4 for f_ in sink.flat) if sink is not None else 0),
            "exchange_exposed_ms_per_step": exposed_ms}
+    # the instrumented step runs on EVERY rank (it contains the gradient exchange: rank 0 alone would wait for its peers forever); rank 0 reads its own report
+    rows = kernel_breakdown(None, None, 1, fn=step)
     if rank == 0:
-        rows = kernel_breakdown(None, None, 1, fn=step)
         sym = {}
         for r in rows:
             a_ = sym.setdefault(r["kernel"].split(" ")[0], {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0})
@@ -428,6 +430,8 @@ def self_launch(n_gpus: int, bench_args, device_count=None) -> int:
     """Re-run this script as N ranks (one per GPU); returns the launcher's exit code.  A box with fewer than N GPUs is a clear
     error, not a hang at the rendezvous."""
     have = torch.cuda.device_count() if device_count is None else device_count
+    if os.environ.get("UF_BENCH_SHARE_GPU") == "1" and device_count is None:
+        have = max(have, n_gpus) if have >= 1 else have       # functional test of the N-rank path on a 1-GPU box (see main): ranks share device 0
     if have < n_gpus:
         raise SystemExit(f"bench.py --gpus {n_gpus}: this node exposes {have} GPU(s) to this process "
                          f"(HIP_VISIBLE_DEVICES={os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')}); run with --gpus <= {max(have, 1)}")
@@ -477,11 +481,16 @@ def main():
     from uformer_amd import dist as ud
     from uformer_amd import spec
 
-    rank, local_rank, world = ud.init_process_group("nccl")
+    # UF_BENCH_BACKEND=gloo UF_BENCH_SHARE_GPU=1: functional test of the N-rank code path (launcher, sharding, gradient sink, JSON assembly) on a box with ONE
+    # GPU -- every rank uses device 0 and the collectives go through gloo; the numbers of such a run mean nothing and the line says so
+    backend = os.environ.get("UF_BENCH_BACKEND", "nccl")
+    share = os.environ.get("UF_BENCH_SHARE_GPU") == "1"
+    rank, local_rank, world = ud.init_process_group(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     cd = TORCH_DTYPE[args.dtype]
 
     cfg = spec.arch_config(args.arch, img_size=args.img)
@@ -509,6 +518,8 @@ def main():
         try:
             train_entry = train_mode(args, cfg, sd, dev, ud, args.train_dtype)
         except Exception as e:      # noqa: BLE001 -- the headline (inference) line must survive a failure of the companion mode; the error is reported in it
+            import traceback
+            print(f"[bench rank {rank}] modes.train failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
             train_entry = {"error": f"{type(e).__name__}: {e}"[:500]}
             torch.cuda.empty_cache()
 
@@ -529,7 +540,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"batch-sharded replicas x{world}, no collective",
                        "ranks": world, "world_size_reported_by_process_group": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "rank_devices": [{"rank": r[0], "local_rank": r[1], "device_index": r[2], "device_id_hash": r[3]} for r in devices],
-                       "collective_backend": "RCCL (torch.distributed nccl backend): barrier + max/sum of the timings + the rank_devices all-gather only"},
+                       "collective_backend": ("RCCL (torch.distributed nccl backend): barrier + max/sum of the timings + the rank_devices all-gather only" if backend == "nccl" else
+                                              f"{backend} (FUNCTIONAL TEST of the N-rank path{', ranks share one GPU' if share else ''}: not a scaling measurement)")},
             "model_gflop_per_image": flops_img / 1e9,
             "mfma_frac_whole_model": value * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[args.dtype],
             "kernel_source_sha": kernel_source_sha(),
