@@ -104,9 +104,10 @@ def main():
                           "peak_mem_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "ranks": world,
                           "rank_devices": devices, "hip_graph": bool(a.graph),
                           "gradient_exchange": "none (1 GPU)" if world == 1 else f"RCCL all-reduce, {len(sink.buckets)} buckets overlapped with the reverse sweep"}))
-    if a.kernels_json and rank == 0:
+    if a.kernels_json:                   # every rank runs the instrumented step (it contains the gradient exchange); rank 0 writes its report
         import bench
         rows = bench.kernel_breakdown(None, None, 1, fn=step)
+    if a.kernels_json and rank == 0:
         os.makedirs(os.path.dirname(os.path.abspath(a.kernels_json)), exist_ok=True)
         with open(a.kernels_json, "w") as f:
             json.dump(rows, f, indent=0)
