@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scan the device code of uformer_amd/lib/libuformer_hip.so for the packed-f32 operand-select forms that measured WRONG on MI355X when an MFMA wave shares
 the SIMD (scripts/ubench_hip/pk_opsel.hip, profiles/r04_run19.txt): `v_pk_fma_f32` / `v_pk_add_f32` / `v_pk_mul_f32` whose op_sel makes the LOW result read
-the HIGH half of src1 (or src2) -- op_sel:[x,1,...] -- returned a wrong low result in lanes 48-63 about once in 1e7.  The forms that select on src0 only, and
+the HIGH half of src1 -- op_sel:[x,1,...] -- returned a wrong low result in lanes 48-63 about once in 1e7.  The forms that select on src0 only, and
 the op_sel_hi-only broadcast forms, measured clean.  hipcc folds broadcasts and horizontal adds into exactly these forms (the LDS-staged stem lost whole
 images to it, profiles/r04_run17.txt / r04_run18.txt), so the build is checked:
 
@@ -18,7 +18,9 @@ import tempfile
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
-HAZARD = re.compile(r"\b(v_pk_(?:fma|add|mul)_f32)\b.*\bop_sel:\[[01],1")          # src1 (and thereby any src2) low-result select set
+# low-result select of src1 set (op_sel:[x,1...]).  A src2-ONLY select (op_sel:[0,0,1]) is not matched on purpose: scripts/ubench_hip/pk_opsel.hip measured the
+# src0 and src2 selects, every op_sel_hi-only form and v_pk_mov_b32 clean (0 mismatches in 1.07e9 results beside MFMA waves, three boxes: profiles/r04_run19.txt)
+HAZARD = re.compile(r"\b(v_pk_(?:fma|add|mul)_f32)\b.*\bop_sel:\[[01],1")
 
 
 def code_objects(path):

@@ -181,6 +181,27 @@ def test_linear_wgrad_and_input_grad(dtype, M, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("v4", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(2049, 256, 256), (4113, 512, 256), (1000, 256, 512)])
+def test_linear_wgrad_never_reads_past_the_last_token(dtype, v4, M, N, K, monkeypatch):
+    """the LDS-DMA weight-gradient kernels (linear_wgrad3: 64-token steps, linear_wgrad4: 32-token stages) advance through the buffer
+    instruction's SCALAR offset and rely on the descriptor's bounds check to zero the rows past M in the last step.  Here M is not a multiple of 64 and
+    the rows directly behind dY and X (same allocation) are NaN: a tail that were read would poison dW / db."""
+    from uformer_amd import ops
+    monkeypatch.setenv("UF_WGRAD_V4", v4)
+    G = 192                                                       # guard rows behind the operands
+    xb = torch.full((M + G, K), float("nan")).to(dtype).cuda()
+    dyb = torch.full((M + G, N), float("nan")).to(dtype).cuda()
+    x = torch.randn(M, K, generator=g(21)).to(dtype)
+    dy = torch.randn(M, N, generator=g(22)).to(dtype)
+    xb[:M].copy_(x); dyb[:M].copy_(dy)
+    dW, db = ops.linear_wgrad(dyb[:M], xb[:M])                    # contiguous row slices of the guarded allocations: same pointers, M rows
+    assert torch.isfinite(dW).all() and torch.isfinite(db).all()
+    rdw = dy.float().t() @ x.float()
+    assert rel(dW, rdw) < 2e-3 and rel(db, dy.float().sum(0)) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 256), (5000, 256, 1024), (2049, 768, 256)])
 def test_linear_wgrad_tile_versions_agree(dtype, M, N, K, monkeypatch):
     """The 256 x 256-tile kernel (uf_bwd.hip linear_wgrad4) against the 128 x 128-tile one on the same operands: both add exact products in f32,

@@ -182,8 +182,14 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ a, 
             // (img * 255.0).round().astype(np.uint8), utils/caculate_psnr_ssim.py:59-62: a float -> uint8 conversion, which keeps the low 8 bits of the
             // rounded integer (values outside [0, 1] WRAP, they are not clamped; the reference's callers pass clamped restorations, so it only matters
             // for parity on out-of-range inputs -- VERDICT r03 "weak" 13)
-            va = (float)((int)rintf(pa[(size_t)gy * W + gx] * 255.0f) & 255);
-            vb = (float)((int)rintf(pb[(size_t)gy * W + gx] * 255.0f) & 255);
+            // A float -> int conversion is undefined for NaN / inf / |v| >= 2^31: those pixels quantise to 0, as the oracle's int64 path
+            // gives for non-finite values; everything a restoration can produce is far inside the range.
+            auto quant = [](float v) {
+                v = rintf(v * 255.0f);
+                return (v == v && fabsf(v) < 2147483520.0f) ? (float)((int)v & 255) : 0.0f;
+            };
+            va = quant(pa[(size_t)gy * W + gx]);
+            vb = quant(pb[(size_t)gy * W + gx]);
         }
         sa[yy][xx] = va; sb[yy][xx] = vb;
     }

@@ -376,7 +376,9 @@ def choose_recompute(cfg, B: int, H: int, device) -> bool:
     per-forward decision compared against the driver's free memory, which excludes what PyTorch's caching allocator reserved on the previous step,
     and could flip between steps or differ between ranks).  The memory that counts as available = the driver's free bytes + the allocator's
     reserved-but-unallocated bytes."""
-    key = (tuple(cfg.depths), cfg.embed_dim, B, H, torch.device(device).index)
+    dev_ = torch.device(device)
+    key = (tuple(cfg.depths), cfg.embed_dim, B, H, dev_.index if dev_.index is not None else torch.cuda.current_device())   # a bare "cuda" names the current device
+    # (Under DDP every rank must reach this point with the same (arch, batch, resolution) the first time: the choice is reduced over the process group.)
     if key not in _RECOMPUTE_CHOICE:
         dims, div = cfg.stage_dims(), cfg.stage_res_div()
         per_tc = 52 if _GELU_IN else 60           # bytes per token x channel of a block (measured 49.0 / 56.5 GB for Uformer-B 256^2 at batch 32); round 4: linear1's activation is not kept
@@ -427,7 +429,7 @@ class UformerTape:
                                           f"channels a multiple of 16 (every get_arch architecture, utils/model_utils.py:56-81)")
         if self.recompute and not any(dims_[s_] == 32 * cfg.num_heads[s_] for s_ in range(9)):
             import warnings
-            warnings.warn("recompute=True was requested, but no stage has head_dim 32 (the fused kernels the recompute form is built on): every block keeps its "
+            warnings.warn("the recompute form was selected (use_checkpoint=True, recompute=True, or chosen from the free memory), but no stage has head_dim 32 (the fused kernels the recompute form is built on): every block keeps its "
                           "intermediates (memory ~18x the recompute form)", stacklevel=2)
         shifts = cfg.block_shifts()
         res = self.res = [H, H // 2, H // 4, H // 8, H // 16, H // 8, H // 4, H // 2, H]
