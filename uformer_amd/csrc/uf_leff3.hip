@@ -18,6 +18,10 @@
 //   epilogue: + bias (x DropPath scale) + x1 rows -> xo.
 // Out of place by construction: the halo rows a tile normalises belong to its neighbours, which must not have been updated yet.
 // 2-byte operand types only (the f32 parity mode keeps the three-kernel path).
+//
+// STATUS (round 5): parity-tested (tests/test_gpu_ops.py::test_leff_halo_recompute; the reference's block fixtures under UF_LEFF3=1) and
+// MEASURED SLOWER than attn_block(+fc1) + leff2 at both widths -- the stages it targets are bound by VALU issue, and the halo costs 1.75 x the linear1 /
+// GELU / LN2 work -- so whole-block calls take it only with UF_LEFF3=1; uf_leff_halo_fwd reaches it directly.
 #include <stdlib.h>
 
 #include "uf_internal.h"
