@@ -189,11 +189,16 @@ int uf_lewin_attn_fwd(const uf_block_params* p, float* x, int ld, int B, int H, 
 /* ---- a10/a11: FFN half (model.py:987): x = x + LeFF(LN2(x)) ; in place. */
 int uf_leff_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
                 uf_dtype dtype, void* ws, size_t ws_bytes, void* stream);
-/* ---- a10 with the hidden tensor recomputed on the tile halo (round 5; 2-byte operands, C = 32 or 64): xo = x1 + LeFF(LN2(x1)) in ONE kernel,
- * OUT OF PLACE (a tile normalises rows of its neighbours) -- h1 = GELU(linear1(LN2 x1)) never exists in HBM (model.py:666-685, :987).
- * uf_leff_fwd / uf_lewin_block_fwd take this path by themselves where it applies. */
-int uf_leff_halo_fwd(const uf_block_params* p, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C,
-                     uf_dtype dtype, void* stream);
+/* ---- a15, training forward of the attention half + linear1 (round 6; 2-byte operands, head_dim 32): the fused window kernel of
+ * uf_lewin_attn_fwd with SIDE STORES of every operand the backward reads, so that the kept-intermediates training forward
+ * (train/train_denoise.py:180-184 over model.py:951-987, :657-658) is one launch instead of six:
+ *   x1 [M][ld1] f32 = x + drop_attn[b] * proj(attention(...))   (out of place: x stays for the LayerNorm backward)
+ *   xn, o  T[M][C] in window-row order; q (times head_dim^-0.5), k T[nW][heads][64][32]; vt T[nW][heads][32][64]   (= uf_ln_qkv_fwd / uf_window_attention_fwd)
+ *   z = LN2(x1) T[M][C] and a1 = linear1(z) + b1 T[M][4C] (PRE-activation; the stencil applies GELU as it loads it) in token order.
+ * drop_attn: per-image DropPath scales (B) or NULL. */
+int uf_lewin_attn_train_fwd(const uf_block_params* p, const float* x, int ld, float* x1, int ld1, int B, int H, int W, int C,
+                            const float* drop_attn, uf_dtype dtype, void* xn, void* q, void* k, void* vt, void* o, void* z, void* a1,
+                            void* stream);
 /* whole block = the two halves */
 int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C,
                        const float* user_mask, int n_mask, uf_dtype dtype, void* ws,

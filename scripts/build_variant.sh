@@ -11,7 +11,7 @@ while [ $# -ge 2 ]; do
     src=$out/$f; [ -f $src ] || cp $R/uformer_amd/csrc/$f $src
     sed -i "$expr" $src; patched[$f]=1
 done
-for f in uf_core uf_gemm uf_lngemm uf_leff2 uf_leff3 uf_attnblk uf_attn uf_elementwise uf_bwd uf_train uf_trainblk uf_pack uf_model; do
+for f in uf_core uf_gemm uf_lngemm uf_leff2 uf_attnblk uf_attn uf_elementwise uf_bwd uf_train uf_trainblk uf_pack uf_model; do
     if [ -n "${patched[$f.hip]}" ]; then
         sed -i "s|#include \"uf_internal.h\"|#include \"$R/uformer_amd/csrc/uf_internal.h\"|; s|#include \"uf_common.h\"|#include \"$R/uformer_amd/csrc/uf_common.h\"|" $out/$f.hip
         /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c $out/$f.hip -o $out/$f.o

@@ -34,8 +34,12 @@ def main():
     ap.add_argument("--loss-scale", type=float, default=0.0, help="static loss scale (default: 65536 for f16 = GradScaler's initial scale, 1 otherwise)")
     ap.add_argument("--kernels-json", default=None, help="also run ONE instrumented step (HIP events around every library launch) and write the per-(kernel, shape) table here")
     ap.add_argument("--graph", action="store_true", help="capture forward + backward of one step in a HIP graph (torch.cuda.CUDAGraph) and replay it; AdamW stays outside (its step count is a launch argument)")
+    ap.add_argument("--no-fused-attn", action="store_true", help="A/B: the op-by-op attention half of the kept-intermediates forward (round-5 form) instead of uf_lewin_attn_train_fwd")
     ap.add_argument("--sink", action="store_true", help="use the bucket-view gradient sink on one GPU too (exercises the overlapped path without a collective)")
     a = ap.parse_args()
+    if a.no_fused_attn:
+        from uformer_amd import train as _train
+        _train._FUSED_ATTN_FWD = False
     rank, local_rank, world = ud.init_process_group("nccl")
     torch.cuda.set_device(local_rank)
     torch.manual_seed(1234 + rank)                                                 # DropPath masks differ per rank (train/train_denoise.py:60-63 seeds 1234)

@@ -13,9 +13,10 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 constexpr int ITER = 2048, UNR = 8;
 
-enum Op { FMA, PKFMA, EXP, RCP, CVTPK, AND, PERM, MFMA16, PKMUL, LDSR, FMA_DEP, MIX_GELU };
+enum Op { FMA, PKFMA, EXP, RCP, CVTPK, AND, PERM, MFMA16, PKMUL, LDSR, FMA_DEP, MIX_GELU, PKFMA16, CVTPKH, GELU_H, GELU_HB };
 static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_cvt_pk_bf16_f32", "v_and_b32", "v_perm_b32", "mfma16x16x32bf16",
-                              "v_pk_mul_f32", "ds_read_b128", "v_fma_f32 dependent", "gelu mix (5pk+4trans)"};
+                              "v_pk_mul_f32", "ds_read_b128", "v_fma_f32 dependent", "gelu mix (5pk+4trans)", "v_pk_fma_f16", "v_cvt_pk_f16_f32",
+                              "gelu pk-f16 poly (1cvt+11pk16) per pair", "gelu pk-f16 poly -> bf16 (+2cvt32+1cvtpk) per pair"};
 
 template <int OP> __device__ __forceinline__ void body(float (&a)[UNR], f32x2 (&p)[UNR], f32x4 (&acc)[UNR], unsigned (&u)[UNR], const char* lds) {
 #pragma unroll
@@ -35,6 +36,15 @@ template <int OP> __device__ __forceinline__ void body(float (&a)[UNR], f32x2 (&
         } else if constexpr (OP == LDSR) {
             f32x4 v = *reinterpret_cast<const f32x4*>(lds + ((threadIdx.x * 16 + k * 1024) & 16383));
             asm volatile("" :: "v"(v));
+        } else if constexpr (OP == PKFMA16) asm volatile("v_pk_fma_f16 %0, %0, %0, %0" : "+v"(u[k]));
+        else if constexpr (OP == CVTPKH) asm volatile("v_cvt_pk_f16_f32 %0, %1, %1" : "=v"(u[k]) : "v"(a[k]));
+        else if constexpr (OP == GELU_H || OP == GELU_HB) {   // round 6: FMA-only GELU of a PAIR in packed f16 (clamp, t^2, degree-6 Horner, t q + 0.5, x *)
+            asm volatile("v_cvt_pk_f16_f32 %0, %1, %2\n\tv_pk_max_f16 %3, %0, %0\n\tv_pk_min_f16 %3, %3, %3\n\tv_pk_mul_f16 %0, %3, %3\n\t"
+                         "v_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_fma_f16 %3, %0, %3, %3\n\t"
+                         "v_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_fma_f16 %3, %0, %3, %3\n\tv_pk_mul_f16 %0, %0, %3"
+                         : "+v"(u[k]), "+v"(a[k]), "+v"(a[(k + 1) % UNR]), "+v"(u[(k + 3) % UNR]));
+            if constexpr (OP == GELU_HB)
+                asm volatile("v_cvt_f32_f16 %1, %0\n\tv_cvt_f32_f16 %2, %0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(u[k]), "+v"(a[k]), "+v"(a[(k + 1) % UNR]));
         } else if constexpr (OP == MIX_GELU) {      // the packed sigmoid-form GELU of the kernels on a pair: 5 packed + 2 exp + 2 rcp
             asm volatile("v_pk_mul_f32 %0, %0, %0\n\tv_pk_fma_f32 %0, %0, %0, %0\n\tv_pk_mul_f32 %0, %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\t"
                          "v_pk_add_f32 %0, %0, %0\n\tv_rcp_f32 %1, %1\n\tv_rcp_f32 %2, %2\n\tv_pk_mul_f32 %0, %0, %0" : "+v"(p[k]), "+v"(a[k]), "+v"(a[(k + 1) % UNR]));
@@ -75,7 +85,8 @@ template <int OPA, int OPB> void run(const char* what, int waves, int wa, unsign
     float ms; hipEventElapsedTime(&ms, e0, e1);
     unsigned long long h[16]; hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     // cycles per instruction of ONE wave of each role (s_memtime), and aggregate instructions per cycle per SIMD for role A / role B
-    const double n = (double)ITER * UNR * (OPA == MIX_GELU ? 9 : 1), nb = (double)ITER * UNR * (OPB == MIX_GELU ? 9 : 1);
+    auto per = [](int op) { return op == MIX_GELU ? 9 : (op == GELU_H ? 12 : (op == GELU_HB ? 15 : 1)); };
+    const double n = (double)ITER * UNR * per(OPA), nb = (double)ITER * UNR * per(OPB);
     const double ca = (double)h[0] / n, cb = wa < waves ? (double)h[wa] / nb : 0;
     const int per_simd_a = (wa + 3) / 4, per_simd_b = (waves - wa + 3) / 4;
     printf("%-44s waves/CU %2d (A %d/SIMD, B %d/SIMD)  A: %6.2f cyc/instr/wave -> %5.2f cyc/instr/SIMD", what, waves, per_simd_a, per_simd_b, ca, ca / per_simd_a);
@@ -86,7 +97,7 @@ template <int OPA, int OPB> void run(const char* what, int waves, int wa, unsign
 #define SOLO(OP) for (int w : {4, 8, 12, 16}) run<OP, OP>(names[OP], w, w, d);
 int main() {
     unsigned long long* d; hipMalloc(&d, 8 * 4096); hipMemset(d, 0, 8 * 4096);
-    SOLO(FMA) SOLO(FMA_DEP) SOLO(PKFMA) SOLO(PKMUL) SOLO(EXP) SOLO(RCP) SOLO(CVTPK) SOLO(AND) SOLO(PERM) SOLO(MFMA16) SOLO(LDSR) SOLO(MIX_GELU)
+    SOLO(FMA) SOLO(FMA_DEP) SOLO(PKFMA) SOLO(PKMUL) SOLO(EXP) SOLO(RCP) SOLO(CVTPK) SOLO(AND) SOLO(PERM) SOLO(MFMA16) SOLO(LDSR) SOLO(MIX_GELU) SOLO(PKFMA16) SOLO(CVTPKH) SOLO(GELU_H) SOLO(GELU_HB)
     printf("--- side by side: role A on waves 0-3, role B on waves 4-7 (one of each per SIMD)\n");
     run<MFMA16, FMA>("A mfma | B v_fma_f32", 8, 4, d);
     run<MFMA16, PKFMA>("A mfma | B v_pk_fma_f32", 8, 4, d);
@@ -96,5 +107,6 @@ int main() {
     run<FMA, EXP>("A v_fma_f32 | B v_exp_f32", 8, 4, d);
     run<FMA, LDSR>("A v_fma_f32 | B ds_read_b128", 8, 4, d);
     run<MFMA16, MIX_GELU>("A mfma (4) | B gelu mix (8)", 12, 4, d);
+    run<MFMA16, GELU_H>("A mfma | B gelu pk-f16 poly", 8, 4, d);
     return 0;
 }

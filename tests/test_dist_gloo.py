@@ -112,7 +112,7 @@ def test_two_rank_gradient_allreduce_matches_single_process():
     assert err < 1e-4 and err3 < 1e-5 and nb > 3
 
 
-def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None):
+def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None, algorithm="ring", payload="float32"):
     """OverlappedGradientAllReduce driven the way UformerTape.backward drives it: gradients arrive stage by stage in reverse-sweep
     order (head, decoder 3..0, bottleneck, encoder 3..0, stem), every bucket is reduced the moment its last gradient is in, p.grad
     is a view of the bucket, and the average is folded into the optimizer's grad_scale."""
@@ -136,7 +136,7 @@ def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None):
     a, b = ud.shard_batch(gb, rank, world)
     mine = grads_of(x[a:b], tgt[a:b], world * (b - a) / gb)
     params = {k: torch.nn.Parameter(v.detach().clone()) for k, v in mine.items()}
-    sink = ud.OverlappedGradientAllReduce(list(params.items()), bucket_bytes=256 << 10)
+    sink = ud.OverlappedGradientAllReduce(list(params.items()), bucket_bytes=256 << 10, algorithm=algorithm, payload=getattr(torch, payload))
     assert all(p.grad is not None and p.grad.data_ptr() == sink.views[k].data_ptr() for k, p in params.items())
     stages = ["output_proj", "decoderlayer_3", "upsample_3", "decoderlayer_2", "upsample_2", "decoderlayer_1", "upsample_1", "decoderlayer_0", "upsample_0",
               "conv", "dowsample_3", "encoderlayer_3", "dowsample_2", "encoderlayer_2", "dowsample_1", "encoderlayer_1", "dowsample_0", "encoderlayer_0",
@@ -169,6 +169,11 @@ def _overlap_worker(rank, world, port, q, gb=2, dropped_by_rank=None):
     for k, p in params.items():
         got = p.grad * sink.grad_scale
         err = max(err, float((got - want[k]).abs().max() / max(float(want[k].abs().max()), 1e-30)))
+    # replicas must hold the SAME bits after the exchange (a 2-byte wire type rounds the reduced slice once, for its owner too)
+    digest = torch.cat([p.grad.reshape(-1) for p in params.values()]).double()
+    sums = [None] * world
+    dist.all_gather_object(sums, (float(digest.sum()), float((digest * digest).sum())))
+    assert all(s_ == sums[0] for s_ in sums), sums
     if rank == 0:
         nodrop = all(not v for v in dropped_by_rank.values())
         if nodrop or world == 2:      # also against the single-process gradient of the whole batch where no rank dropped that tensor
@@ -213,3 +218,36 @@ def test_three_rank_overlapped_allreduce_uneven_droppath_masks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1e-5 and nb > 3 and order[0] == 0
+
+
+def test_two_rank_direct_exchange_equals_the_allreduce():
+    """algorithm="direct" (all_to_all_single + f32 sum on receipt + all_gather_into_tensor) with an f32 wire type: the same gradients as the
+    bucketed all-reduce, the same launch order, replicas bit-identical."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q, 2, None, "direct", "float32")) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, nb, order = q.get(timeout=400)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1e-4 and nb > 3 and order[0] == 0
+
+
+def test_three_rank_direct_exchange_bf16_wire_f32_accumulation():
+    """Three ranks (a world that does not divide the bucket: padded slices), bf16 on the wire, uneven DropPath masks: within bf16 rounding of the f32
+    all-reduce (two roundings: the sender's slice and the reduced slice), and every rank ends with identical bits."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    dropped = {0: [], 1: ["encoderlayer_2.blocks.0.mlp.linear1.0.weight"], 2: ["conv.blocks.0.norm1.bias"]}
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 3, port, q, 3, dropped, "direct", "bfloat16")) for r in range(3)]
+    for p in procs:
+        p.start()
+    err, nb, order = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err < 1.2e-2 and nb > 3 and order[0] == 0

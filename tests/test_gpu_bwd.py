@@ -822,3 +822,56 @@ def test_standalone_block_module_is_differentiable(golden, dtype):
     assert rel(x.grad / ls, t(gd["dx"])) < tol
     for n, p_ in blk.named_parameters():
         assert rel(p_.grad / ls, t(gd["g." + n])) < tol, n
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("prefix,C,heads,shift,B,H", [("encoderlayer_0.blocks.0.", 32, 1, 0, 2, 32), ("decoderlayer_3.blocks.0.", 64, 2, 4, 3, 16),
+                                                      ("encoderlayer_2.blocks.1.", 128, 4, 4, 2, 16), ("decoderlayer_1.blocks.1.", 256, 8, 4, 1, 16),
+                                                      ("decoderlayer_1.blocks.0.", 256, 8, 0, 5, 64), ("decoderlayer_0.blocks.1.", 512, 16, 4, 2, 8)])
+def test_fused_attention_training_forward_equals_the_inference_kernel_and_the_op_by_op_forward(dtype, prefix, C, heads, shift, B, H):
+    """uf_lewin_attn_train_fwd (round 6: the fused window kernel with side stores of what the backward reads): its residual rows are the bits of the
+    inference kernel (uf_lewin_attn_fwd: same MFMAs on the same operands), and every stored operand -- xn, q, k, v^T, o (window rows), z, a1 (token
+    rows) -- agrees with the op-by-op forward (layernorm -> qkv -> window_attention_core -> linear_residual -> layernorm -> linear) to the rounding of
+    the operand type.  Widths 32 ... 512, both launch shapes of C = 256 (<= 256 and > 256 windows), shifted and unshifted, with and without modulator."""
+    import ctypes
+    from uformer_amd import _lib, ops, spec, train
+    cfg = spec.arch_config("Uformer_B", 128)
+    sd = {k: v.cuda() for k, v in spec.synth_state_dict(cfg, 21).items() if k.startswith(prefix)}
+    assert sd[prefix + "norm1.weight"].numel() == C
+    pk = train.NativeBlockPack(sd, prefix, heads, shift, dtype)
+    x = (torch.randn(B * H * H, C, generator=g(200)) * 1.3).cuda()
+    drop = (torch.rand(2, B, generator=g(201)) > 0.3).float().cuda() * 1.25
+    M = B * H * H
+    x1, xn, q, k, vt, o, z, a1 = ops.lewin_attn_train_fwd(pk.fused, x, B, H, H, heads, dtype, drop[0])
+    # (1) residual rows without DropPath scales (uf_lewin_attn_fwd takes none): bit-identical to the inference kernel
+    lib = _lib.load()
+    xin = x.clone()
+    dt = ops.uf_dtype(dtype)
+    nbytes = lib.uf_block_workspace_bytes(M, C, dt)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    x1_nodrop, *_ = ops.lewin_attn_train_fwd(pk.fused, x, B, H, H, heads, dtype, None)
+    _lib.check(lib.uf_lewin_attn_fwd(ctypes.byref(pk.fused), xin.data_ptr(), C, B, H, H, C, None, 0, dt, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream), "uf_lewin_attn_fwd")
+    assert torch.equal(x1_nodrop, xin)
+    assert torch.equal(x, (torch.randn(B * H * H, C, generator=g(200)) * 1.3).cuda())      # the input rows are untouched (out of place)
+    # (2) against the op-by-op forward
+    monkey = train._FUSED_ATTN_FWD
+    train._FUSED_ATTN_FWD = False
+    try:
+        y_ref, sv = train.lewin_block_forward(x.reshape(B, H * H, C), sd, prefix, heads, shift, dtype, drop, pk)
+    finally:
+        train._FUSED_ATTN_FWD = monkey
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+    for name, got in (("x1", x1), ("xn", xn), ("q", q), ("k", k), ("vt", vt), ("o", o), ("z", z), ("a1", a1)):
+        ref = sv[name].float().cpu()
+        assert got.shape == sv[name].shape and got.dtype == sv[name].dtype, name
+        assert rel(got, ref) < tol, (name, rel(got, ref))
+    # (3) the block forward built on it and its backward agree with the op-by-op pair to the same rounding
+    y_f, sv_f = train.lewin_block_forward(x.reshape(B, H * H, C), sd, prefix, heads, shift, dtype, drop, pk)
+    assert rel(y_f, y_ref.float().cpu()) < tol
+    dy = torch.randn(B, H * H, C, generator=g(202)).cuda()
+    dx_f, g_f = train.lewin_block_backward(sv_f, dy)
+    dx_r, g_r = train.lewin_block_backward(sv, dy)
+    assert rel(dx_f, dx_r.float().cpu()) < 2 * tol
+    for name in g_r:
+        if g_r[name].abs().max() > 0:
+            assert rel(g_f[name], g_r[name].float().cpu()) < 2 * tol, name

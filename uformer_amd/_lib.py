@@ -105,7 +105,7 @@ SIGNATURES = {
     "uf_block_workspace_bytes": (c_size_t, [I, I, I]),
     "uf_lewin_attn_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
     "uf_leff_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, I, P, c_size_t, P]),
-    "uf_leff_halo_fwd": (I, [C.POINTER(BlockParams), P, I, P, I, I, I, I, I, I, P]),
+    "uf_lewin_attn_train_fwd": (I, [C.POINTER(BlockParams), P, I, P, I, I, I, I, I, P, I, P, P, P, P, P, P, P, P]),
     "uf_lewin_block_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
     "uf_lewin_block_train_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, P, I, P, c_size_t, P]),
     "uf_downsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),

@@ -40,8 +40,13 @@ struct AttnBlkParams {
     const void* W1; const float* b1;
     void* h1;                              // T[B*H*W][4C] or NULL
     const float* drop;                     // training: per-image DropPath scale of this branch (bernoulli(keep)/keep, model.py:986) or NULL
+    // TR = 1 (training forward that keeps what the backward reads): xn / o T[M][C] in window-row order, q / k T[nW][heads][64][32] (q times
+    // head_dim^-0.5), v^T T[nW][heads][32][64] -- the layouts of uf_ln_qkv_fwd / uf_window_attention_fwd, read by uf_linear_wgrad and
+    // uf_window_attention_bwd -- and z = LN2(x1) T[M][C] in token order; h1 then receives the PRE-activation of linear1 (a1)
+    void* s_xn; void* s_q; void* s_k; void* s_vt; void* s_o; void* s_z;
     int n_windows, H, W, shift;
     float qscale;
+    float qscale_plain;                    // head_dim^-0.5 without the log2(e) of the softmax domain: the q the backward reads
     unsigned long long* tbuf;   // optional phase timestamps (uf_debug_set_tbuf)
 };
 
@@ -134,7 +139,7 @@ template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // bala
 // permlane-widened direct 16-byte stores.  2-byte operand types only.
 // Fc1Walk::first(): the weight fragments of the wave's first unit (callable before the operand tile exists: UF_HOIST);
 // Fc1Walk::run(): the walk.
-template <typename T, int C, int WAVES, int UW = 4>
+template <typename T, int C, int WAVES, int UW = 4, bool ACT = true>   // ACT = false: the pre-activation is stored (training: the backward needs GELU'(a1))
 struct Fc1Walk {
     static_assert(UW == 4 || UW == 2, "units of 64 x 64 or 64 x 32");
     static constexpr int SZ = sizeof(T), KS = C / 32, RING = KS >= 8 ? UF_FC1_RING : (KS >= 4 ? 4 : 3), N4 = 4 * C, UNITS = N4 / (16 * UW);
@@ -204,7 +209,7 @@ struct Fc1Walk {
 #pragma unroll
             for (int ip = 0; ip < UW; ip += 2) {
                 f32x4 va = acc[ip][j] + bv[ip], vb = acc[ip + 1][j] + bv[ip + 1];
-                if (UF_ABL != 8) { gelu4<T>(va); gelu4<T>(vb); }
+                if (UF_ABL != 8 && ACT) { gelu4<T>(va); gelu4<T>(vb); }
                 const unsigned a0 = pack2<T>(va[0], va[1]), a1 = pack2<T>(va[2], va[3]);
                 const unsigned c0 = pack2<T>(vb[0], vb[1]), c1 = pack2<T>(vb[2], vb[3]);
                 const u32x2_t s0 = __builtin_amdgcn_permlane16_swap(a0, c0, false, false);
@@ -230,7 +235,7 @@ struct NoWalk {   // f32 operands: phase 3 does not exist
 // <= 96 / 128 / 168, i.e. 5 / 4 / 3 workgroups per CU instead of 4 / 3 / 2.  These widths are bound by how many independent windows a
 // CU holds (a wave issues one instruction per ~5.3 cycles and waits on LDS / L2 round trips between its phases).  Same
 // MFMAs on the same operands in the same order per accumulator: bit-identical results to LR = 0.
-template <typename T, int C, int NT, int LR = 0>
+template <typename T, int C, int NT, int LR = 0, int TR = 0>
 __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : ((sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2))) void attn_block_kernel(const AttnBlkParams p) {
     constexpr int SZ = sizeof(T);
     constexpr int WAVES = NT / 64;
@@ -392,6 +397,17 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
     stamp(1);
     lds_barrier();
     stamp(2);
+    // TR: an LDS operand tile [64][C] -> global rows, 16-byte pieces, consecutive threads on consecutive pieces of a row
+    auto tile_out = [&](const char* tile, void* dst, bool token_order) {
+        constexpr int PPR = C * SZ / 16;
+#pragma unroll 4
+        for (int i = tid; i < 64 * PPR; i += NT) {
+            const int r = i / PPR, pc = i - r * PPR;
+            const size_t row = token_order ? (size_t)window_token(geo, r) : (size_t)bw * 64 + r;
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(dst) + (row * C * SZ + pc * 16)) = *reinterpret_cast<const u32x4*>(tile + r * SA + pc * 16);
+        }
+    };
+    if constexpr (TR) tile_out(Xn, p.s_xn, false);
 
     // SW-MSA mask predicate of this window (model.py:924-942), evaluated in registers
     const int nWc = p.W >> 3, nW = (p.H >> 3) * nWc;
@@ -560,6 +576,33 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
                 FragFromAcc<T>::make(vtf[0][sk], av[0][2 * sk] + bv0, av[0][2 * sk + 1] + bv0);
                 FragFromAcc<T>::make(vtf[1][sk], av[1][2 * sk] + bv1, av[1][2 * sk + 1] + bv1);
             }
+            if constexpr (TR && SZ == 2) {
+                // what the backward reads, in the layouts of the three-kernel path: q = T((xn Wq^T + bq) head_dim^-0.5) (its own rounding: the
+                // fragment above carries log2(e) as well), k and v^T straight from the operand fragments (8 bytes = 4 channels / 4 tokens per lane)
+                const size_t wh = (size_t)bw * HEADS + h;
+                T* qb = reinterpret_cast<T*>(p.s_q) + wh * 2048;
+#pragma unroll
+                for (int j = 0; j < QT; ++j) {
+                    store4(qb + ((q0 + j) * 16 + fr) * 32 + fg * 4, (aq[0][j] + bq0) * p.qscale_plain);
+                    store4(qb + ((q0 + j) * 16 + fr) * 32 + 16 + fg * 4, (aq[1][j] + bq1) * p.qscale_plain);
+                }
+                if (q0 == 0) {              // units of one head differ only in their query tiles: the first one writes the head's k and v
+                    T* kb = reinterpret_cast<T*>(p.s_k) + wh * 2048;
+                    T* vb = reinterpret_cast<T*>(p.s_vt) + wh * 2048;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        *reinterpret_cast<u32x2*>(kb + (j * 16 + fr) * 32 + fg * 4) = u32x2{kf[j].v[0], kf[j].v[1]};
+                        *reinterpret_cast<u32x2*>(kb + (j * 16 + fr) * 32 + 16 + fg * 4) = u32x2{kf[j].v[2], kf[j].v[3]};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int sk = 0; sk < 2; ++sk) {
+                            *reinterpret_cast<u32x2*>(vb + (i * 16 + fr) * 64 + (2 * sk) * 16 + fg * 4) = u32x2{vtf[i][sk].v[0], vtf[i][sk].v[1]};
+                            *reinterpret_cast<u32x2*>(vb + (i * 16 + fr) * 64 + (2 * sk + 1) * 16 + fg * 4) = u32x2{vtf[i][sk].v[2], vtf[i][sk].v[3]};
+                        }
+                }
+            }
         }
         }
         // S^T = K Q^T : s[kt][j] -> lane: query (q0+j)*16+fr, keys 16kt+4fg+r
@@ -662,7 +705,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         if (u == wave) stamp(4);
     }
     stamp(5);
-    std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES, LR ? 2 : 4>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
+    std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES, LR ? 2 : 4, TR == 0>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
     // ---------------- phase 2: proj + window_reverse + roll back + residual ---------------------------
     {
         constexpr int WN = (C / 16) < WAVES ? (C / 16) : WAVES, WM = WAVES / WN;
@@ -713,6 +756,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         if constexpr (HOIST) proj_requests();      // in flight across the barrier (UF_HOIST): waves that finish phase 1 early wait there anyway
         lds_barrier();
         stamp(6);
+        if constexpr (TR) tile_out(Os, p.s_o, false);
         if constexpr (!HOIST) proj_requests();
         aload(0, 0);
 #pragma unroll
@@ -800,6 +844,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         if (p.h1) {
             lds_barrier();
             stamp(11);
+            if constexpr (TR) tile_out(Xn, p.s_z, true);
             if constexpr (!HOIST) fc1w.first(reinterpret_cast<const T*>(p.W1), wave, lane);
             fc1w.run(Xn, SA, p.b1, reinterpret_cast<T*>(p.h1), geo, wave);
             stamp(12);
@@ -808,16 +853,16 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
     census.end(p.tbuf, bw);
 }
 
-template <typename T, int C, int NT, int LR = 0>
+template <typename T, int C, int NT, int LR = 0, int TR = 0>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
     constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    auto kern = attn_block_kernel<T, C, NT, LR>;
+    auto kern = attn_block_kernel<T, C, NT, LR, TR>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "attn_block")) return rc;
     char name[96] = "";
     if (timing_enabled())
-        snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", p.h1 ? "_fc1" : "", TypeName<T>::s, C, NT, p.n_windows * 64, C);
+        snprintf(name, sizeof(name), "attn_block%s_%s_c%d_nt%d %dx%d", TR ? "_train" : (p.h1 ? "_fc1" : ""), TypeName<T>::s, C, NT, p.n_windows * 64, C);
     const double M = (double)p.n_windows * 64;
     const double fc1_flops = p.h1 ? 2.0 * M * C * 4.0 * C : 0.0, fc1_bytes = p.h1 ? M * 4.0 * C * sizeof(T) + 4.0 * C * C * sizeof(T) : 0.0;
     {
@@ -892,6 +937,44 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
 #undef UF_AB_HALF
 #undef UF_AB
     set_error("attn_block: unsupported C=%d for dtype %d", C, (int)dtype);
+    return UF_ERR_UNSUPPORTED;
+}
+
+
+// Training forward of the attention half + linear1: the fused kernel with side stores of every operand the
+// backward reads, x1 out of place (the block's input stays for the LayerNorm backward).  2-byte operand types, head_dim 32.
+int launch_attn_block_train(const uf_block_params* bp, const float* x, int ld, float* x1, int ld1, int B, int H, int W, int C, uf_dtype dtype, const float* drop,
+                            void* xn, void* q, void* k, void* vt, void* o, void* z, void* a1, hipStream_t st) {
+    AttnBlkParams p{};
+    p.drop = drop;
+    p.x = const_cast<float*>(x); p.ld = ld;            // read only: xo != x
+    p.xo = x1; p.ldo = ld1; p.gamma = bp->norm1_w; p.beta = bp->norm1_b; p.modulator = bp->modulator;
+    p.Wqkv = bp->wqkv_fm; p.bqkv = bp->bqkv; p.rpb_tab = bp->rpb_tab;
+    p.Wp = bp->wproj_fm; p.bp = bp->bproj;
+    p.gamma2 = bp->norm2_w; p.beta2 = bp->norm2_b; p.W1 = bp->w1_fm; p.b1 = bp->b1;
+    p.h1 = a1;
+    p.s_xn = xn; p.s_q = q; p.s_k = k; p.s_vt = vt; p.s_o = o; p.s_z = z;
+    p.n_windows = B * (H / 8) * (W / 8); p.H = H; p.W = W; p.shift = bp->shift;
+    p.qscale_plain = (float)(1.0 / sqrt(32.0));
+    p.qscale = p.qscale_plain * LOG2E;
+    p.tbuf = debug_get_tbuf();
+#define UF_ABT(TT)                                                                                          \
+        switch (C) {                                                                                        \
+            case 32: return launch_one<TT, 32, 256, 0, 1>(p, st);                                           \
+            case 64: return launch_one<TT, 64, 256, 0, 1>(p, st);                                           \
+            case 128: return launch_one<TT, 128, 256, 0, 1>(p, st);                                         \
+            case 256:                                                                                       \
+                if (p.n_windows <= 256) return launch_one<TT, 256, 512, 0, 1>(p, st);                       \
+                return launch_one<TT, 256, 256, 0, 1>(p, st);                                               \
+            case 512: return launch_one<TT, 512, 512, 0, 1>(p, st);                                         \
+        }
+    if (dtype == UF_BF16) {
+        UF_ABT(bf16)
+    } else if (dtype == UF_F16) {
+        UF_ABT(f16)
+    }
+#undef UF_ABT
+    set_error("attn_block (training form): unsupported C=%d for dtype %d (bf16 / f16 operands, C = 32 ... 512)", C, (int)dtype);
     return UF_ERR_UNSUPPORTED;
 }
 

@@ -48,18 +48,15 @@ void debug_set_tbuf(void* p);
 bool attn_block_supported(const uf_block_params* bp, const float* user_mask, uf_dtype dtype, int C, int heads);
 // h1_out != NULL (and dtype bf16): the kernel also writes h1 = GELU(linear1(LN2(x_new))), T[B*H*W][4C]
 // drop: per-image DropPath scale of the attention branch (training forward) or NULL
-// xo / ldo (optional): write the new rows THERE instead of in place (the halo-recompute LeFF kernel reads its neighbours' rows of x1, so the
-// block then runs x -> x1 (scratch) -> x)
+// xo / ldo (optional): write the new rows THERE instead of in place
 int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, void* h1_out, hipStream_t st,
                       const float* drop = nullptr, float* xo = nullptr, int ldo = 0);
 // second half of LeFF with an optional per-image DropPath scale of the branch (uf_leff2.hip)
 int launch_leff2(const void* h1, const float* w9, const float* bdw, const void* W2, const float* b2, float* x, int ld, int B, int H, int W, int C,
                  uf_dtype dtype, const float* drop, hipStream_t st);
 
-// the whole LeFF half in one kernel with h1 recomputed on the tile halo (uf_leff3.hip): xo = x1 + DropPath(LeFF(LN2(x1))), out of place
-bool leff3_covers(uf_dtype dtype, int C);      // shapes the kernel is built for
-bool leff3_supported(uf_dtype dtype, int C);   // ... and whole-block calls select it (UF_LEFF3=1; off by default, see uf_leff3.hip)
-int launch_leff3(const uf_block_params* bp, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,
-                 const float* drop, hipStream_t st);
+// training forward of the attention half + linear1: the fused kernel with side stores of what the backward reads (uf_attnblk.hip)
+int launch_attn_block_train(const uf_block_params* bp, const float* x, int ld, float* x1, int ld1, int B, int H, int W, int C, uf_dtype dtype, const float* drop,
+                            void* xn, void* q, void* k, void* vt, void* o, void* z, void* a1, hipStream_t st);
 
 }  // namespace uf

@@ -51,12 +51,6 @@ int check_block_args(const uf_block_params* p, const float* x, int ld, int B, in
 }
 
 // fc1_done (optional): set when the fused kernel also produced the LeFF hidden h1 in w.h1 (whole-block calls only)
-// whole-block calls at the HBM-bound widths (2-byte operands, C = 32 / 64): attn_block writes x1 to the scratch, leff3 recomputes the hidden tensor on its
-// tile halo and writes the block's result back to x -- h1 never exists in HBM (uf_leff3.hip)
-bool halo_block(const uf_block_params* p, const float* user_mask, uf_dtype dtype, int C) {
-    return leff3_supported(dtype, C) && attn_block_supported(p, user_mask, dtype, C, p->heads);
-}
-
 int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask, uf_dtype dtype,
               const BlockWs& w, hipStream_t st, const float* drop_attn, const float* drop_leff);
 
@@ -97,13 +91,6 @@ int attn_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, uf_dtype dtype, const BlockWs& w,
               hipStream_t st, bool fc1_done = false, const float* drop = nullptr) {
     const int M = B * H * W;
-    if (!fc1_done && leff3_supported(dtype, C)) {
-        // the half on its own (uf_leff_fwd): leff3 is out of place, so the rows go to the scratch first
-        float* x1 = reinterpret_cast<float*>(w.h1);
-        UF_REQUIRE(hipMemcpy2DAsync(x1, (size_t)C * 4, x, (size_t)ld * 4, (size_t)C * 4, (size_t)M, hipMemcpyDeviceToDevice, st) == hipSuccess, UF_ERR_LAUNCH,
-                   "leff: copy of the stream rows failed");
-        return launch_leff3(p, x1, C, x, ld, B, H, W, C, dtype, drop, st);
-    }
     // LN2 -> linear1 -> GELU, one kernel                 (model.py:987, :657-658, :671) unless the attention kernel did it
     if (!fc1_done) {
         int rc = uf_ln_linear_gelu_fwd(x, ld, p->norm2_w, p->norm2_b, p->w1_fm, p->b1, w.h1, M, 4 * C, C, dtype, st);
@@ -116,12 +103,6 @@ int leff_half(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 
 int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* user_mask, int n_mask, uf_dtype dtype,
               const BlockWs& w, hipStream_t st, const float* drop_attn, const float* drop_leff) {
-    if (halo_block(p, user_mask, dtype, C)) {
-        float* x1 = reinterpret_cast<float*>(w.h1);            // f32 [M][C]: half the bytes of the h1 region it replaces
-        int rc = launch_attn_block(p, x, ld, B, H, W, C, dtype, nullptr, st, drop_attn, x1, C);
-        if (rc) return rc;
-        return launch_leff3(p, x1, C, x, ld, B, H, W, C, dtype, drop_leff, st);
-    }
     bool fc1_done = false;
     int rc = attn_half(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, st, &fc1_done, drop_attn);
     if (rc) return rc;
@@ -132,13 +113,6 @@ int block_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, i
 }  // namespace uf
 
 using namespace uf;
-
-extern "C" int uf_leff_halo_fwd(const uf_block_params* p, const float* x1, int ld1, float* xo, int ldo, int B, int H, int W, int C, uf_dtype dtype,
-                                void* stream) {
-    UF_REQUIRE(p, UF_ERR_NULL, "uf_leff_halo_fwd: null pointer");
-    UF_REQUIRE(leff3_covers(dtype, C), UF_ERR_UNSUPPORTED, "uf_leff_halo_fwd: bf16 / f16 operands at C = 32 or 64 (got dtype %d, C = %d)", (int)dtype, C);
-    return launch_leff3(p, x1, ld1, xo, ldo, B, H, W, C, dtype, nullptr, (hipStream_t)stream);
-}
 
 extern "C" size_t uf_block_workspace_bytes(int M, int C, uf_dtype dtype) {
     if (M <= 0 || C <= 0) return 0;
@@ -173,6 +147,20 @@ extern "C" int uf_lewin_block_fwd(const uf_block_params* p, float* x, int ld, in
     rc = carve(w, ws, ws_bytes, (size_t)B * H * W, C, dtype);
     if (rc) return rc;
     return block_fwd(p, x, ld, B, H, W, C, user_mask, n_mask, dtype, w, (hipStream_t)stream, nullptr, nullptr);
+}
+
+extern "C" int uf_lewin_attn_train_fwd(const uf_block_params* p, const float* x, int ld, float* x1, int ld1, int B, int H, int W, int C,
+                                       const float* drop_attn, uf_dtype dtype, void* xn, void* q, void* k, void* vt, void* o, void* z, void* a1,
+                                       void* stream) {
+    int rc = check_block_args(p, x, ld, B, H, W, C, dtype);
+    if (rc) return rc;
+    UF_REQUIRE(x1 && xn && q && k && vt && o && z && a1, UF_ERR_NULL, "uf_lewin_attn_train_fwd: null output pointer");
+    UF_REQUIRE(x1 != x && ld1 >= C && ld1 % 4 == 0, UF_ERR_SHAPE, "uf_lewin_attn_train_fwd: x1 must be out of place, ld1=%d", ld1);
+    UF_REQUIRE(dtype_half(dtype) && attn_block_supported(p, nullptr, dtype, C, p->heads), UF_ERR_UNSUPPORTED,
+               "uf_lewin_attn_train_fwd: bf16 / f16 operands, head_dim 32, C = 32 ... 512 and the compact bias table (got dtype %d, C=%d, heads=%d)", (int)dtype, C, p->heads);
+    const uintptr_t al = (uintptr_t)x1 | (uintptr_t)xn | (uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o | (uintptr_t)z | (uintptr_t)a1;
+    UF_REQUIRE((al % 16) == 0, UF_ERR_ALIGN, "uf_lewin_attn_train_fwd: outputs must be 16-byte aligned");
+    return launch_attn_block_train(p, x, ld, x1, ld1, B, H, W, C, dtype, drop_attn, xn, q, k, vt, o, z, a1, (hipStream_t)stream);
 }
 
 extern "C" int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int ld, int B, int H, int W, int C, const float* drop_attn,

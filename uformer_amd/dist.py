@@ -177,7 +177,21 @@ class OverlappedGradientAllReduce:
     ``sink.begin_step(); loss.backward(); sink.finish(); opt.step(grad_scale=sink.grad_scale)``.  ``begin_step`` may be omitted
     (the first gradient after ``finish`` starts a new step); ``begin_step(accumulate=k)`` announces k backward passes per step."""
 
-    def __init__(self, model_or_named_params, bucket_bytes: int = 25 << 20):
+    def __init__(self, model_or_named_params, bucket_bytes: int = 25 << 20, algorithm: str = "ring", payload: torch.dtype = torch.float32):
+        """``algorithm``: "ring" = one ``dist.all_reduce`` per bucket (RCCL / gloo pick the schedule: a ring over xGMI is bound by ONE link per hop);
+        "direct" (xGMI is a full point-to-point mesh, 7 links per GPU) = reduce-scatter by ``all_to_all_single`` -- every rank sends
+        slice j of the bucket straight to rank j over its own link -- an f32 sum of the world slices on the receiver, and ``all_gather_into_tensor``
+        of the reduced slices: two steps over all links at once instead of 2 (world - 1) ring hops.
+        ``payload`` (direct only): the wire type.  torch.bfloat16 halves the bytes on the links (101.8 MB instead of 203.5 MB per step for Uformer-B);
+        the slices are ACCUMULATED IN F32 on receipt and the reduced slice is rounded once more for the gather, identically on every rank (the
+        owner of a slice uses the rounded values too: replicas stay bit-identical)."""
+        if algorithm not in ("ring", "direct"):
+            raise ValueError("algorithm must be 'ring' or 'direct'")
+        if payload not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("payload must be float32, bfloat16 or float16")
+        if payload != torch.float32 and algorithm != "direct":
+            raise ValueError("a 2-byte payload needs algorithm='direct' (a ring all-reduce would ACCUMULATE in the wire type)")
+        self.algorithm, self.payload = algorithm, payload
         named = list(model_or_named_params.named_parameters()) if hasattr(model_or_named_params, "named_parameters") else list(model_or_named_params)
         named = [(n, p) for n, p in named if p.requires_grad][::-1]
         self.names = [n for n, _ in named]
@@ -196,7 +210,9 @@ class OverlappedGradientAllReduce:
         self.flat, self.views = [], {}
         for b, idxs in enumerate(self.buckets):
             dev = self.params[idxs[0]].device
-            flat = torch.zeros(sum(self.params[i].numel() for i in idxs), dtype=torch.float32, device=dev)
+            n_el = sum(self.params[i].numel() for i in idxs)
+            n_pad = (n_el + 255) // 256 * 256           # "direct": the bucket splits into `world` equal slices (any world that divides 256: 1, 2, 4, 8, ...; others pad at launch)
+            flat = torch.zeros(n_pad, dtype=torch.float32, device=dev)
             self.flat.append(flat)
             off = 0
             for i in idxs:
@@ -207,6 +223,8 @@ class OverlappedGradientAllReduce:
                 p.grad = v                                         # the optimizer reads the bucket directly
                 off += p.numel()
         self.launch_order = []                                     # bucket indices in the order their collectives were issued (tests)
+        self._stage = {}                                           # "direct": per-bucket staging buffers (send / receive / reduced slice / gathered), made once
+        self._xs = None                                            # "direct" on a GPU: the stream the two-step exchange is chained on
         self.begin_step()
 
     @property
@@ -238,7 +256,46 @@ class OverlappedGradientAllReduce:
         self._launched.add(b)
         self.launch_order.append(b)
         if self.world > 1:
-            self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+            if self.algorithm == "direct":
+                self._direct(b)
+            else:
+                self._works.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wire_bytes_per_step(self) -> int:
+        """bytes one rank puts on its links per step (both directions count once): ring all-reduce 2 (w-1)/w N 4, direct 2 (w-1)/w N sizeof(payload)"""
+        w = self.world
+        if w <= 1:
+            return 0
+        n = sum(int(f.numel()) for f in self.flat)
+        return int(2 * (w - 1) / w * n * (4 if self.algorithm == "ring" else torch.empty(0, dtype=self.payload).element_size()))
+
+    def _direct(self, b: int) -> None:
+        """reduce-scatter by all-to-all + f32 accumulation on receipt + all-gather of the reduced slices, chained on a side stream (GPU) so that
+        the compute stream goes on with the reverse sweep; finish() joins the stream"""
+        flat, w = self.flat[b], self.world
+        n = flat.numel()
+        npad = (n + w - 1) // w * w
+        st = self._stage.get(b)
+        if st is None or st["w"] != w:
+            st = self._stage[b] = dict(w=w, send=torch.zeros(npad, dtype=self.payload, device=flat.device), recv=torch.empty(npad, dtype=self.payload, device=flat.device),
+                                       mine=torch.empty(npad // w, dtype=self.payload, device=flat.device), out=torch.empty(npad, dtype=self.payload, device=flat.device))
+
+        def exchange():
+            st["send"][:n].copy_(flat)                                             # f32 -> payload (a plain copy for f32)
+            dist.all_to_all_single(st["recv"], st["send"])                         # recv[j] = rank j's copy of MY slice
+            red = st["recv"].view(w, npad // w).to(torch.float32).sum(0)          # accumulated in f32 whatever the wire type
+            st["mine"].copy_(red)                                                  # rounded ONCE to the wire type: every rank, the owner included, uses these values
+            dist.all_gather_into_tensor(st["out"], st["mine"])
+            flat.copy_(st["out"][:n])                                              # back into the bucket param.grad views
+
+        if flat.is_cuda:
+            if self._xs is None:
+                self._xs = torch.cuda.Stream(device=flat.device)
+            self._xs.wait_stream(torch.cuda.current_stream(flat.device))           # behind the kernels that produced the bucket's last gradient
+            with torch.cuda.stream(self._xs):
+                exchange()                                                         # RCCL enqueues on its own stream; this stream waits for it (no host block)
+        else:
+            exchange()
 
     def deliver(self, grads) -> None:
         """grads: {parameter name: gradient tensor or None}.  None (a branch DropPath removed on this rank) counts as zeros: the
@@ -294,6 +351,8 @@ class OverlappedGradientAllReduce:
         for w in self._works:
             w.wait()
         self._works = []
+        if self._xs is not None:
+            torch.cuda.current_stream(self.flat[0].device).wait_stream(self._xs)
         self._finished = True                                      # the next deliver() starts a fresh step
         for i, p in enumerate(self.params):                        # autograd may have replaced .grad: point it back at the bucket
             if p.grad is None or p.grad.data_ptr() != self.views[self.names[i]].data_ptr():

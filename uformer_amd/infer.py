@@ -116,7 +116,8 @@ class GraphedForward:
     (the library's own side-stream fork / join is followed by the capture, tests/test_gpu_model.py::test_forward_captured_in_a_hip_graph) and
     ``__call__`` copies the new batch into the static input buffer and replays -- bit-identical to the eager forward.  The returned tensor
     is the graph's static output: clone it if it must survive the next call.  Weights are read at replay time (the graph holds
-    pointers into the packed-weight buffers): call ``recapture()`` after the model's parameters changed."""
+    pointers into the packed-weight buffers): ``__call__`` compares the model's packed-weight cache (keyed by (storage, version) of every parameter) with the one it
+    captured and recaptures by itself when the parameters changed; the captured pack is kept alive by this object, so a stale replay can never read freed memory."""
 
     def __init__(self, model, example: Tensor):
         if not example.is_cuda:
@@ -137,11 +138,22 @@ class GraphedForward:
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph, stream=st):
             self._y = self.model(self._x)
+        # the graph holds raw pointers into THIS pack: keep it alive (an eager forward after a parameter change repacks and would free it under the
+        # graph), and remember which pack it is so that __call__ notices the change
+        self._captured_pack = self._current_pack()
+
+    def _current_pack(self):
+        get = getattr(self.model, "_get_packed", None)
+        return get(self._x.device) if get is not None else None
 
     @torch.no_grad()
     def __call__(self, x: Tensor) -> Tensor:
         if x.shape != self._x.shape or x.dtype != self._x.dtype or x.device != self._x.device:
             raise ValueError(f"GraphedForward was captured for {tuple(self._x.shape)} {self._x.dtype} on {self._x.device}, got {tuple(x.shape)} {x.dtype} on {x.device}")
+        if self._current_pack() is not self._captured_pack:
+            # parameters changed since the capture (optimizer step, load_state_dict, .to()): _get_packed has just repacked them into NEW buffers, the
+            # graph would replay on the old ones and return stale results -- capture again
+            self.recapture()
         self._x.copy_(x)
         self._graph.replay()
         return self._y

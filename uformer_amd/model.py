@@ -568,7 +568,9 @@ class Uformer(nn.Module):
         # (model.py:1056-1057: torch.utils.checkpoint around every block) = the recompute form: a block keeps only its input
         names = train.NamesWithSink(names)
         names.sink = sink
-        names.recompute = True if self.use_checkpoint else None
+        # (2-byte operand types only: compute_dtype=float32 always keeps its intermediates -- UformerTape's rule; the f32 fused forward + op-level
+        #  recomputation pair is a combination no fixture covers)
+        names.recompute = True if (self.use_checkpoint and self.compute_dtype in (torch.bfloat16, torch.float16)) else None
         rates = self.drop_path_rates() if self.training else []      # eval(): DropPath is the identity (timm)
         drop = getattr(self, "_drop_scales_override", None) if self.training else None
         if drop is None and any(r > 0 for r in rates):

@@ -502,16 +502,26 @@ def dwconv_linear2(h1: Tensor, w9: Tensor, bdw: Tensor, w2: Tensor, b2: Tensor, 
     return out
 
 
-def leff_halo(bp, x1: Tensor, B: int, H: int, W: int, dtype) -> Tensor:
-    """x1 + LeFF(LN2(x1)) in ONE kernel with the hidden tensor recomputed on the tile halo (uf_leff_halo_fwd; model.py:666-685, :987).
-    bp: _lib.BlockParams (packing.pack_block); x1 f32 (B*H*W, C); 2-byte operand types, C = 32 or 64.  Out of place."""
-    _dev(x1)
-    x1 = _c(x1, torch.float32)
-    Cc = x1.shape[-1]
-    out = torch.empty_like(x1)
-    with torch.cuda.device(x1.device):
-        _lib.check(_lib.load().uf_leff_halo_fwd(bp, _ptr(x1), Cc, _ptr(out), Cc, B, H, W, Cc, uf_dtype(dtype), _stream()), "uf_leff_halo_fwd")
-    return out
+def lewin_attn_train_fwd(bp, x: Tensor, B: int, H: int, W: int, heads: int, dtype, drop_attn: Optional[Tensor] = None):
+    """Training forward of the attention half + linear1 of a LeWin block in ONE launch (uf_lewin_attn_train_fwd; model.py:951-987, :657-658): the fused
+    window kernel with side stores of what the backward reads.  bp: _lib.BlockParams (the fused pack); x f32 (B*H*W, C), untouched.
+    Returns (x1 f32 (M, C), xn, q, k, vt, o, z, a1) in the layouts of layernorm(windowed) / qkv / window_attention_core / layernorm / linear."""
+    _dev(x, drop_attn)
+    x = _c(x, torch.float32)
+    M, Cc = x.shape
+    T, hd = torch_dtype(uf_dtype(dtype)), Cc // heads
+    dev = x.device
+    x1 = torch.empty_like(x)
+    xn, o, z = (torch.empty((M, Cc), dtype=T, device=dev) for _ in range(3))
+    q = torch.empty((M // 64, heads, 64, hd), dtype=T, device=dev)
+    k = torch.empty_like(q)
+    vt = torch.empty((M // 64, heads, hd, 64), dtype=T, device=dev)
+    a1 = torch.empty((M, 4 * Cc), dtype=T, device=dev)
+    da = None if drop_attn is None else _c(drop_attn, torch.float32)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().uf_lewin_attn_train_fwd(bp, _ptr(x), Cc, _ptr(x1), Cc, B, H, W, Cc, _ptr(da), uf_dtype(dtype), _ptr(xn), _ptr(q), _ptr(k), _ptr(vt),
+                                                       _ptr(o), _ptr(z), _ptr(a1), _stream()), "uf_lewin_attn_train_fwd")
+    return x1, xn, q, k, vt, o, z, a1
 
 
 def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int) -> Tensor:

@@ -81,12 +81,14 @@ class AdamW(torch.optim.Optimizer):
         """The step under a device-resident dynamic loss scale: every parameter shares the scaler's count of steps actually taken (a skipped step does
         not advance it), the per-parameter ``step`` entries of the state dict are refreshed from it by ``GradScaler.sync_steps`` (``state_dict()`` and a
         later plain ``step()`` do that by themselves).  The first scaled step after construction, after ``load_state_dict`` or after plain steps SEEDS the
-        scaler's count from the optimizer's own ``step`` entries when they are ahead (a reference checkpoint carries the optimizer but no scaler,
+        scaler's count from the optimizer's own ``step`` entries (when the optimizer has any: a reference checkpoint carries the optimizer but no scaler,
         train/train_denoise.py:207-235): bias corrections continue at step N + 1 instead of restarting at 1 on populated moments."""
         if self._scaler is not scaler:
             loaded = self._loaded_step()
             if loaded > 0:
-                scaler.state[4:5].clamp_(min=float(loaded))       # device-side max: no host synchronisation
+                # the loaded / plain-step count is the authority (ADVICE r05: a max() kept a live scaler's LARGER count after the optimizer was rolled back to an
+                # earlier checkpoint, and corrupted the saved 'step' entries afterwards); device-side fill, no host synchronisation
+                scaler.state[4:5].fill_(float(loaded))
             self._scaler = scaler
         for group in self.param_groups:
             ps, gs, ms, vs = [], [], [], []

@@ -168,19 +168,26 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
     H = W = int(math.sqrt(L))
     M = B * L
     T = dtype
-    pk = pk or BlockPack(p, prefix, heads, shift, T, fused=False)
+    pk = pk or BlockPack(p, prefix, heads, shift, T, fused=fused_attn_covers(T, C, heads))
     f = lambda k: p[prefix + k]                                             # noqa: E731
     x2 = x.reshape(M, C).float().contiguous()
-    xn = ops.layernorm(x2, f("norm1.weight"), f("norm1.bias"), B=B, H=H, W=W, dtype=T, windowed=True, shift=shift, modulator=pk.mod)
-    q, k, vt = ops.qkv(xn, pk.wqkv, pk.bqkv, heads)                          # window rows; q already scaled
-    o = ops.window_attention_core(q, k, vt, pk.bias, H=H, W=W, shift=shift)  # (M, C) window rows
     s1 = drop[0].float().contiguous() if drop is not None else None         # per-sample DropPath scales (B,)
     s2 = drop[1].float().contiguous() if drop is not None else None
-    # x + DropPath(window_reverse(proj(o))): the residual add, the scale and the un-partition in the projection GEMM's store   model.py:975-986
-    x1 = ops.linear_residual(o, pk.wp, f("attn.proj.bias"), x2, s1, B, H, W, windowed=True, shift=shift)
-    z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
-    if _GELU_IN:     # linear1 keeps only its pre-activation (the backward needs that one); the stencil activates it as it loads it
-        a1 = ops.linear(z, pk.w1, f("mlp.linear1.0.bias"))
+    fused_attn = fused_attn_covers(T, C, heads) and getattr(pk, "fused", None) is not None
+    if fused_attn:
+        # round 6: LN1 -> q/k/v -> attention -> proj + residual -> LN2 -> linear1 in ONE launch (the fused window kernel of the inference path) with side
+        # stores of every operand the backward reads, instead of the six launches below and their round trips through HBM
+        x1, xn, q, k, vt, o, z, a1 = ops.lewin_attn_train_fwd(pk.fused, x2, B, H, W, heads, T, s1)
+    else:
+        xn = ops.layernorm(x2, f("norm1.weight"), f("norm1.bias"), B=B, H=H, W=W, dtype=T, windowed=True, shift=shift, modulator=pk.mod)
+        q, k, vt = ops.qkv(xn, pk.wqkv, pk.bqkv, heads)                          # window rows; q already scaled
+        o = ops.window_attention_core(q, k, vt, pk.bias, H=H, W=W, shift=shift)  # (M, C) window rows
+        # x + DropPath(window_reverse(proj(o))): the residual add, the scale and the un-partition in the projection GEMM's store   model.py:975-986
+        x1 = ops.linear_residual(o, pk.wp, f("attn.proj.bias"), x2, s1, B, H, W, windowed=True, shift=shift)
+        z = ops.layernorm(x1, f("norm2.weight"), f("norm2.bias"), B=B, H=H, W=W, dtype=T)
+    if fused_attn or _GELU_IN:     # linear1 keeps only its pre-activation (the backward needs that one); the stencil activates it as it loads it
+        if not fused_attn:
+            a1 = ops.linear(z, pk.w1, f("mlp.linear1.0.bias"))
         h1 = None
         c, g2 = ops.dwconv3x3_pre_gelu(a1.reshape(B, H, W, 4 * C), pk.w9, f("mlp.dwconv.0.bias"), gelu_in=True)
     else:
@@ -197,6 +204,14 @@ def lewin_block_forward(x: Tensor, p: Dict[str, Tensor], prefix: str, heads: int
 
 
 _SIDE_STREAMS: Dict[str, list] = {}
+_FUSED_ATTN_FWD = True     # False: the op-by-op attention half of the kept-intermediates forward (tests compare the two)
+
+
+def fused_attn_covers(T: torch.dtype, C: int, heads: int) -> bool:
+    """shapes uf_lewin_attn_train_fwd is built for: 2-byte operands, head_dim 32, C = 32 ... 512"""
+    return _FUSED_ATTN_FWD and T in (torch.bfloat16, torch.float16) and C == 32 * heads and C in (32, 64, 128, 256, 512)
+
+
 # module attributes, not environment switches (round 5): the shipped forms; the alternatives stay reachable for tests / A-B runs by setting the attribute
 _GELU_IN = True            # False: linear1 writes pre-activation AND activation, the stencil reads the latter
 _DW_BWD_FUSED = True       # False: the two-kernel depthwise backward (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad)
@@ -451,7 +466,7 @@ class UformerTape:
                 # uf_pack_block_train (5 launches) covers C % 32 == 0; its pack also serves the op-by-op form as tensor views
                 native = C % 32 == 0 and C % cfg.num_heads[s] == 0 and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
                 pk = self.packs[prefix] = (NativeBlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T) if native else
-                                           BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=fusable))
+                                           BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=fusable or fused_attn_covers(T, C, cfg.num_heads[s])))
                 if fusable:                                                     # fused kernels; the block's input is all that is kept
                     y = ops.lewin_block_train_fwd(pk.fused, t, B, res[s], res[s], T, None if dr is None else dr[0], None if dr is None else dr[1])
                     self.saved_blocks[s].append(dict(x=t, drop=dr, pk=pk))
