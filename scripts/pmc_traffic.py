@@ -18,7 +18,7 @@ src, dst = sys.argv[1], sys.argv[2]
 
 
 def symbol(kernel):
-    m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)(?:, \d+)?>", kernel)                   # <T, C, NT[, LR]>
+    m = re.search(r"attn_block_kernel<uf::bf16, (\d+), (\d+)(?:, \d+)*>", kernel)                   # <T, C, NT[, LR[, TR]]>
     if m:
         return f"attn_block_fc1_bf16_c{m.group(1)}_nt{m.group(2)}"
     m = re.search(r"leff2_kernel<uf::bf16, (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, \d+)?>", kernel)      # <T, C, NPG, NC, NBUF, WPS[, PW[, CP]]>

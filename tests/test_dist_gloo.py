@@ -251,3 +251,85 @@ def test_three_rank_direct_exchange_bf16_wire_f32_accumulation():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert err < 1.2e-2 and nb > 3 and order[0] == 0
+
+
+def _traj_worker(rank, world, port, q, algorithm):
+    """K optimizer steps of data-parallel training through the gradient sink: every rank differentiates the loss of ITS half of the batch (oracle autograd
+    stands in for the HIP backward), the sink exchanges the bucket views that ARE param.grad, and the 1 / world of the average is folded into the update as
+    uf_adamw_step's grad_scale does (here: one scaling of the bucket before torch.optim.AdamW).  Rank 0 also runs the same K steps alone on the whole batch."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import uformer_oracle as O
+    from uformer_amd import dist as ud
+    from uformer_amd import spec
+    torch.set_num_threads(2)
+    ud.init_process_group("gloo")
+    cfg = spec.arch_config("tiny", 128)
+    kw = dict(img_size=128, embed_dim=16, depths=cfg.depths, num_heads=cfg.num_heads)
+    K, gb = 3, 2
+    xs = [spec.synth_input(gb, 128, 128, 60 + k) for k in range(2)]          # two alternating batches, as the reference-trajectory fixture
+    ts = [spec.synth_input(gb, 128, 128, 70 + k) for k in range(2)]
+
+    def run(shard, use_sink):
+        sd0 = spec.synth_state_dict(cfg, 5)
+        params = {k: torch.nn.Parameter(v.clone()) for k, v in sd0.items() if v.is_floating_point()}
+        full = dict(sd0, **params)
+        opt = torch.optim.AdamW(list(params.values()), lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.02)      # train/train_denoise.py:77
+        sink = ud.OverlappedGradientAllReduce(list(params.items()), bucket_bytes=256 << 10, algorithm=algorithm) if use_sink else None
+        losses = []
+        for k in range(K):
+            a, b = shard
+            if sink is not None:
+                sink.begin_step()
+            else:
+                opt.zero_grad(set_to_none=True)
+            loss = O.charbonnier_loss(O.uformer_forward(xs[k % 2][a:b], full, **kw), ts[k % 2][a:b])
+            grads = torch.autograd.grad(loss, list(params.values()))
+            if sink is not None:
+                sink.deliver({n: g_ for n, g_ in zip(params.keys(), grads)})
+                sink.finish()
+                for p in params.values():
+                    assert p.grad.data_ptr() == sink.views[[n for n, q_ in params.items() if q_ is p][0]].data_ptr()
+                for f in sink.flat:
+                    f.mul_(sink.grad_scale)                              # uf_adamw_step(grad_scale = 1 / world) reads the bucket and scales in its registers
+            else:
+                for p, g_ in zip(params.values(), grads):
+                    p.grad = g_
+            opt.step()
+            losses.append(float(loss))
+        return {n: p.detach().clone() for n, p in params.items()}, losses
+
+    a, b = ud.shard_batch(gb, rank, world)
+    mine, my_losses = run((a, b), True)
+    # replicas hold identical weights after K steps
+    digest = float(torch.cat([v.reshape(-1) for v in mine.values()]).double().sum())
+    all_d = [None] * world
+    dist.all_gather_object(all_d, digest)
+    assert all(d == all_d[0] for d in all_d), all_d
+    if rank == 0:
+        ref, ref_losses = run((0, gb), False)
+        err = max(float((mine[n] - ref[n]).abs().max() / max(float(ref[n].abs().max()), 1e-12)) for n in ref)
+        moved = max(float((ref[n] - spec.synth_state_dict(cfg, 5)[n]).abs().max()) for n in ref)
+        q.put((err, moved, my_losses, ref_losses))
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_trajectory_equals_single_process():
+    """bucket views -> exchange -> update with grad_scale = 1 / world over K = 3 steps on 2 ranks x half the batch gives the weights of
+    1 rank x the whole batch (mean loss: the average of the two half-batch gradients IS the full-batch gradient), with the ring all-reduce and with the
+    direct all-to-all exchange."""
+    for algorithm in ("ring", "direct"):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_traj_worker, args=(r, 2, port, q, algorithm)) for r in range(2)]
+        for p in procs:
+            p.start()
+        err, moved, my_losses, ref_losses = q.get(timeout=900)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert moved > 1e-4                       # the weights did move (3 AdamW steps at lr 2e-4)
+        assert err < 2e-5, (algorithm, err)
+        assert len(my_losses) == 3 and len(ref_losses) == 3

@@ -364,7 +364,8 @@ def test_lewin_block_golden(golden, dtype, tag):
 
 def test_leff2_and_attn_block_variants_bit_identical():
     """The launch variants that are chosen by shape (and therefore by batch size) must agree bit for bit, or a batch-16 forward would not equal 16
-    single forwards: leff2 with 8 producer waves / the persistent tile walk, attn_block in its low-register forms.  The
+    single forwards: leff2 with 8 producer waves / the persistent tile walk, attn_block in its low-register forms and (round 6) its
+    single-operand-tile form at C = 256.  The
     switches are read once per process, so every variant runs in a child process and returns hashes of its outputs on the same inputs."""
     import os
     import subprocess
@@ -383,7 +384,7 @@ for (B, H, C) in ((1, 64, 128), (5, 64, 128), (1, 32, 256), (9, 32, 256), (1, 32
     x = torch.randn(B * H * H, C, generator=g).cuda()
     y = ops.dwconv_linear2(h1, w9, bd, w2, b2, x)
     out.append(hashlib.sha256(y.cpu().numpy().tobytes()).hexdigest()[:16])
-for (B, H, C, heads) in ((2, 64, 32, 1), (1, 128, 128, 4), (2, 32, 64, 2)):
+for (B, H, C, heads) in ((2, 64, 32, 1), (1, 128, 128, 4), (2, 32, 64, 2), (5, 64, 256, 8)):      # the last: C = 256 with 320 windows (> 256: the 4-wave forms)
     torch.manual_seed(C + H)
     blk = um.LeWinTransformerBlock(C, (H, H), heads, win_size=8, shift_size=4, modulator=True).cuda().eval()
     xb = torch.randn(B, H * H, C, generator=torch.Generator().manual_seed(3)).cuda()
@@ -396,7 +397,8 @@ print("HASHES " + " ".join(out))
     for tag, env in (("default", {}), ("leff2 8 producers", {"UF_LEFF2_VARIANT": "p"}), ("leff2 never 8 producers", {"UF_LEFF2_VARIANT": "n"}),
                      ("leff2 one tile per workgroup", {"UF_LEFF2_PERSIST": "0"}),
                      ("leff2 tile walk everywhere", {"UF_LEFF2_PERSIST": "1"}), ("attn_block first form", {"UF_ATTN_LR": "0"}),
-                     ("attn_block low-register form", {"UF_ATTN_LR": "1"}), ("attn_block low-register code, first bounds", {"UF_ATTN_LR": "2"})):
+                     ("attn_block low-register form", {"UF_ATTN_LR": "1"}), ("attn_block low-register code, first bounds", {"UF_ATTN_LR": "2"}),
+                     ("attn_block C = 256 two operand tiles", {"UF_ATTN_ST": "0"}), ("attn_block C = 256 single operand tile (O overwrites Xn)", {"UF_ATTN_ST": "1"})):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         line = [l for l in r.stdout.splitlines() if l.startswith("HASHES ")]
         assert r.returncode == 0 and line, (tag, r.stdout[-1500:], r.stderr[-1500:])

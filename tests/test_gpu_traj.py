@@ -22,6 +22,11 @@ pytestmark = pytest.mark.gpu
 # operand rounding shows in the small-gradient elements of a tensor; final weights f32 1.3e-6)
 LOSS_RTOL = {torch.float32: 1e-5, torch.float16: 2e-4, torch.bfloat16: 1e-3}
 DELTA_TOL = {torch.float32: 2e-3, torch.float16: 0.2, torch.bfloat16: 0.6}
+# final weights, relative to the largest weight of the tensor (the projection gates of the 2-byte types are loose -- Adam turns every gradient element
+# into a step of O(lr), so a rounding-level sign flip of a tiny gradient moves a projection by a whole step -- while the WEIGHTS after 8 steps differ from the
+# reference's by at most 8 steps x lr relative to weights of O(1)): measured f32 1.3e-6, f16 7.2e-3, bf16 8.1e-3 (a small-magnitude bias whose elements took
+# opposite steps: 8 x 2e-4 against a largest weight of 0.2) -- the 2-byte gate is twice that saturation level; the step-count assertion below is the sharp one
+FINAL_RTOL = {torch.float32: 1e-5, torch.float16: 1.6e-2, torch.bfloat16: 1.6e-2}
 TAG = {torch.float32: "f32", torch.bfloat16: "bf16", torch.float16: "f16"}
 
 
@@ -79,5 +84,7 @@ def test_eight_step_trajectory_vs_reference_loop(golden, dtype):
         json.dump(rec, f, indent=1)
     assert loss_err < LOSS_RTOL[dtype], rec
     assert worst[0] < DELTA_TOL[dtype], rec
-    if dtype == torch.float32:
-        assert full < 1e-5, rec                                             # final weights within 1e-5 relative (VERDICT r04 "next" 7)
+    assert full < FINAL_RTOL[dtype], rec                                    # final weights (f32: within 1e-5 relative, VERDICT r04 "next" 7)
+    # the optimizer counted every step once (a wrong bias-correction count or a step the scaler skipped silently would pass the loss gate of the 2-byte types)
+    steps_seen = {int(st["step"]) for st in opt.state_dict()["state"].values()}
+    assert steps_seen == {int(g["steps"])}, steps_seen

@@ -102,6 +102,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 #endif
 template <int C> constexpr bool hoist_on() { return (C <= 128 && (UF_HOIST & 1)) || (C == 256 && (UF_HOIST & 2)) || (C == 512 && (UF_HOIST & 4)); }
 
+#ifndef UF_ATTN_ST_DEFAULT
+#define UF_ATTN_ST_DEFAULT false
+#endif
 #ifndef UF_ATTN_LR_DEFAULT
 #define UF_ATTN_LR_DEFAULT 0
 #endif
@@ -122,6 +125,12 @@ template <typename T> __device__ __forceinline__ void wfrag_load(Frag<T>& f, con
 template <typename T> __device__ __forceinline__ void afrag_load(Frag<T>& f, const T* p) {
     if constexpr (UF_ABL == 7 && sizeof(T) == 2) { const unsigned v = 0x3c003c00u ^ (unsigned)(uintptr_t)p; f.v = u32x4{v, v, v, v}; }
     else load_frag(f, p);
+}
+
+// A fragment made from accumulators is COMPUTED HERE (ST form): the IR-level sinking passes otherwise move the bias add + pack down to the first use
+// across the sched_barriers -- the f32 accumulators (twice the registers) then stay alive through the next projection and spill under the 168-register bound
+template <typename T> __device__ __forceinline__ void pin_frag(Frag<T>& f) {
+    if constexpr (sizeof(T) == 2) asm volatile("" : "+v"(f.v));
 }
 
 template <int N> __device__ __forceinline__ float tree_sum(float* v) {   // balanced pairwise sum, N a power of two
@@ -235,8 +244,16 @@ struct NoWalk {   // f32 operands: phase 3 does not exist
 // <= 96 / 128 / 168, i.e. 5 / 4 / 3 workgroups per CU instead of 4 / 3 / 2.  These widths are bound by how many independent windows a
 // CU holds (a wave issues one instruction per ~5.3 cycles and waits on LDS / L2 round trips between its phases).  Same
 // MFMAs on the same operands in the same order per accumulator: bit-identical results to LR = 0.
+// LR = 3 (round 6, C = 256 with 4 waves): the SINGLE-OPERAND-TILE form.  The O tile of phase 1 overwrites the
+// Xn tile instead of living beside it: a wave keeps the outputs of its two heads in 32 registers (packed to the operand type) until every wave of the
+// workgroup has finished its projections -- the last reads of Xn -- and only then are they written, behind a barrier.  LDS 80.9 KB -> 47.1 KB = THREE
+// workgroups per CU by LDS; for three by registers (<= 168) it is built on the low-register walk (LR = 1), normalises two rows per pass in phase 0 instead
+// of four, fetches the residual rows in the epilogue instead of ahead of the k-loop and adds the bias table one diagonal at a time.  Three independent
+// windows per CU = three waves per SIMD whose LayerNorm / softmax / GELU phases (VALU) and load / store bursts overlap each other's MFMAs.  Same MFMAs
+// on the same operands in the same order per accumulator: bit-identical to LR = 0.
 template <typename T, int C, int NT, int LR = 0, int TR = 0>
-__global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : ((sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2))) void attn_block_kernel(const AttnBlkParams p) {
+__global__ __launch_bounds__(NT, LR == 3 ? 3 : (LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : ((sizeof(T) == 2 && C <= 32) ? 4 : ((sizeof(T) == 2 && C == 64) ? 3 : 2)))) void attn_block_kernel(const AttnBlkParams p) {
+    constexpr bool ST = LR == 3;
     constexpr int SZ = sizeof(T);
     constexpr int WAVES = NT / 64;
     constexpr int HEADS = C / 32;
@@ -247,8 +264,8 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
     constexpr int UNITS = HEADS * (4 / QT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Xn = smem;
-    char* Os = smem + 64 * SA;
-    float* Tab = reinterpret_cast<float*>(smem + 2 * 64 * SA);   // [HEADS][225] compact rel-pos bias
+    char* Os = ST ? smem : smem + 64 * SA;                        // ST: O overwrites Xn (behind a barrier, see phase 1)
+    float* Tab = reinterpret_cast<float*>(smem + (ST ? 1 : 2) * 64 * SA);   // [HEADS][225] compact rel-pos bias
     float* Red = Tab + HEADS * 225;                               // [2][WAVES][64] LN2 partial sums (phase 3)
     float* Bq = Red + 2 * WAVES * 64;                             // [3C] q/k/v bias + [C] proj bias: read from LDS inside the unit walks, not from L2
 
@@ -318,7 +335,8 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         constexpr int V4 = C / (4 * LPR);
         constexpr int RPP = NT / LPR;
         constexpr int NP = 64 / RPP;
-        constexpr int U = (16 / V4) < NP ? (16 / V4) : NP;   // 16 x 16-byte loads in flight per thread
+        constexpr int U0 = (16 / V4) < NP ? (16 / V4) : NP;   // 16 x 16-byte loads in flight per thread
+        constexpr int U = (ST && U0 > 2) ? 2 : U0;            // ST: half the rows per pass (x and modulator rows of a pass: 128 -> 64 registers)
         static_assert(NP >= 1 && NP % U == 0, "pass batching");
         const int sub = tid % LPR;
         // the order in which a workgroup walks its rows is rotated by the window index: all workgroups start together, and with
@@ -420,8 +438,10 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
     // pipe during the projections, then both leave it idle during the softmax.  Holding back the second half of the waves by about
     // one projection lets a SIMD run one wave's MFMAs beside the other's VALU work (UF_P1_OFFSET x 64 cycles, 0 = off).
     if (WAVES == 8 && UF_P1_OFFSET > 0 && wave >= 4) __builtin_amdgcn_s_sleep(UF_P1_OFFSET * (C / 256) > 127 ? 127 : UF_P1_OFFSET * (C / 256));
-#pragma unroll 1
-    for (int u = wave; u < UNITS; u += WAVES) {
+    constexpr int UPW = (UNITS + WAVES - 1) / WAVES;             // units per wave
+    static_assert(!ST || (SZ == 2 && UNITS % WAVES == 0), "single-tile form: 2-byte operands, every wave owns the same number of heads");
+    unsigned opk[ST ? UPW : 1][QT][4];                           // ST: the finished heads of this wave, packed, until Xn may be overwritten
+    auto unit = [&](const int u, const int ui) __attribute__((always_inline)) {
         const int h = u / (4 / QT), q0 = (u % (4 / QT)) * QT;   // head, first query tile
         Frag<T> qf[QT], kf[4], vtf[2][2];
         if constexpr (LR) {
@@ -459,7 +479,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) FragFromAcc<T>::make(kf[j], ak[0][j] + bk0, ak[1][j] + bk1);
+                for (int j = 0; j < 4; ++j) { FragFromAcc<T>::make(kf[j], ak[0][j] + bk0, ak[1][j] + bk1); if constexpr (ST) pin_frag(kf[j]); }
             }
             {
                 f32x4 av[2][4];
@@ -484,6 +504,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
                 for (int sk = 0; sk < 2; ++sk) {
                     FragFromAcc<T>::make(vtf[0][sk], av[0][2 * sk] + bv0, av[0][2 * sk + 1] + bv0);
                     FragFromAcc<T>::make(vtf[1][sk], av[1][2 * sk] + bv1, av[1][2 * sk + 1] + bv1);
+                    if constexpr (ST) { pin_frag(vtf[0][sk]); pin_frag(vtf[1][sk]); }
                 }
             }
             {
@@ -623,23 +644,35 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         // exp(s - max) = exp2(s' - max') is one v_sub + v_exp per score (no multiply); the SW-MSA mask
         // (-100, model.py:924-942) becomes -100*log2(e) and is applied only in the windows that have one
         // (last window row / column of a shifted block): a wave-uniform branch, interior windows skip it.
-        f32x4 tb[7];
         {
             const int dyc = (fr >> 3) - (fg >> 1);
             const int xb = 7 - (fr & 7) + 4 * (fg & 1);
             const float* th = Tab + h * 225 + xb;
-#pragma unroll
-            for (int d = 0; d < 7; ++d) {
+            auto tb_row = [&](int d) {
                 int row = 2 * (q0 + d - 3) + dyc + 7;      // dy + 7 for (query tile - key tile) = q0 + d - 3 ... (d = j - kt + 3)
                 row = row < 0 ? 0 : (row > 14 ? 14 : row);  // rows outside [0,14] belong to unused (j,kt) pairs
                 const float* tr = th + row * 15;
-                tb[d] = f32x4{tr[0], tr[1], tr[2], tr[3]};
+                return f32x4{tr[0], tr[1], tr[2], tr[3]};
+            };
+            if constexpr (ST) {           // one diagonal of (query tile, key tile) pairs at a time: 4 registers of table values live instead of 28
+#pragma unroll
+                for (int d = 0; d < 7; ++d) {
+                    const f32x4 tbd = tb_row(d);
+#pragma unroll
+                    for (int j = 0; j < QT; ++j)
+                        if (j + 3 - d >= 0 && j + 3 - d < 4) s[j + 3 - d][j] += tbd;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                f32x4 tb[7];
+#pragma unroll
+                for (int d = 0; d < 7; ++d) tb[d] = tb_row(d);
+#pragma unroll
+                for (int j = 0; j < QT; ++j)
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt) s[kt][j] += tb[j - kt + 3];
             }
         }
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) s[kt][j] += tb[j - kt + 3];
         if (last_r || last_c) {
 #pragma unroll
             for (int j = 0; j < QT; ++j) {
@@ -698,11 +731,37 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
         // head merge (model.py:519): O[token][h*32 + d]
 #pragma unroll
         for (int j = 0; j < QT; ++j) {
-            T* orow = reinterpret_cast<T*>(Os + ((q0 + j) * 16 + fr) * SA) + h * 32 + fg * 4;
-            store4(orow, o[0][j] * inv[j]);
-            store4(orow + 16, o[1][j] * inv[j]);
+            if constexpr (ST) {           // parked in registers: other waves still read Xn, which the O tile overwrites
+                const f32x4 oa = o[0][j] * inv[j], ob = o[1][j] * inv[j];
+                opk[ui][j][0] = pack2<T>(oa[0], oa[1]); opk[ui][j][1] = pack2<T>(oa[2], oa[3]);
+                opk[ui][j][2] = pack2<T>(ob[0], ob[1]); opk[ui][j][3] = pack2<T>(ob[2], ob[3]);
+                // pinned: left to itself the scheduler keeps the 8 f32 accumulators alive across the next unit and packs them at the end (32 spilled registers)
+                asm volatile("" : "+v"(opk[ui][j][0]), "+v"(opk[ui][j][1]), "+v"(opk[ui][j][2]), "+v"(opk[ui][j][3]));
+            } else {
+                T* orow = reinterpret_cast<T*>(Os + ((q0 + j) * 16 + fr) * SA) + h * 32 + fg * 4;
+                store4(orow, o[0][j] * inv[j]);
+                store4(orow + 16, o[1][j] * inv[j]);
+            }
         }
         if (u == wave) stamp(4);
+    };
+    if constexpr (ST) {
+#pragma unroll
+        for (int ui = 0; ui < UPW; ++ui) unit(wave + ui * WAVES, ui);
+        lds_barrier();                                            // every wave has made its last read of Xn
+#pragma unroll
+        for (int ui = 0; ui < UPW; ++ui) {
+            const int u = wave + ui * WAVES, h = u / (4 / QT), q0 = (u % (4 / QT)) * QT;
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                char* orow = Os + ((q0 + j) * 16 + fr) * SA + (h * 32 + fg * 4) * SZ;
+                *reinterpret_cast<u32x2*>(orow) = u32x2{opk[ui][j][0], opk[ui][j][1]};
+                *reinterpret_cast<u32x2*>(orow + 16 * SZ) = u32x2{opk[ui][j][2], opk[ui][j][3]};
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int u = wave; u < UNITS; u += WAVES) unit(u, 0);
     }
     stamp(5);
     std::conditional_t<SZ == 2, Fc1Walk<T, C, WAVES, LR ? 2 : 4, TR == 0>, NoWalk> fc1w;     // phase 3's weight ring: its first fragments are requested in front of LN2 (UF_HOIST)
@@ -738,7 +797,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
             xrow[j] = p.x + tok * p.ld;
             xorow[j] = p.xo + tok * p.ldo;
         }
-        constexpr bool PRE = SZ == 2;
+        constexpr bool PRE = SZ == 2 && !ST;      // ST: 64 registers it does not have
         f32x4 res[PRE ? TNW : 1][PRE ? TMW : 1];
         auto proj_requests = [&]() {       // what does not depend on the O tile: weight prologue, residual rows
 #pragma unroll
@@ -855,7 +914,7 @@ __global__ __launch_bounds__(NT, LR == 1 ? (C <= 32 ? 5 : (C == 64 ? 4 : 3)) : (
 
 template <typename T, int C, int NT, int LR = 0, int TR = 0>
 int launch_one(const AttnBlkParams& p, hipStream_t st) {
-    constexpr int smem = 2 * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
+    constexpr int smem = (LR == 3 ? 1 : 2) * 64 * (C * (int)sizeof(T) + 16) + (C / 32) * 225 * 4 + 2 * (NT / 64) * 64 * 4 + 4 * C * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     auto kern = attn_block_kernel<T, C, NT, LR, TR>;
     static bool lds_done[64] = {};
@@ -911,6 +970,10 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     // on the first form (C = 128 with 1024 windows 0.445 / 0.445 / 0.467, C = 64 0.361 / 0.373 / 0.366 and 0.177 / 0.179 / 0.183).
     static const char* elr = getenv("UF_ATTN_LR");
     const int lr = elr ? atoi(elr) : (C == 32 ? 2 : ((C == 128 && p.n_windows >= 4096) ? 1 : 0));
+    // C = 256 with more windows than one round of workgroups (dec1 at batch >= 8): the single-operand-tile form (LR = 3), three workgroups per CU.
+    // UF_ATTN_ST=0 / 1 forces the two-tile / single-tile form (A/B runs; bit-identical results)
+    static const char* est = getenv("UF_ATTN_ST");
+    const bool st256 = est ? est[0] == '1' : UF_ATTN_ST_DEFAULT;
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
 #define UF_AB_HALF(TT)                                                                                                              \
         switch (C) {                                                                                                                    \
@@ -919,6 +982,7 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
             case 128: if (lr == 1) return launch_one<TT, 128, 256, 1>(p, st); if (lr == 2) return launch_one<TT, 128, 256, 2>(p, st); UF_AB(TT, 128, 256);                                                                                              \
             case 256:                                                                                                                   \
                 if (p.n_windows <= 256) UF_AB(TT, 256, 512);   /* one workgroup per CU at most: 8 waves (one head each) instead of 4 */ \
+                if (st256) return launch_one<TT, 256, 256, 3>(p, st);   /* single-operand-tile form: three workgroups per CU */       \
                 UF_AB(TT, 256, 256);                                                                                                    \
             case 512: UF_AB(TT, 512, 512);                                                                                              \
         }
