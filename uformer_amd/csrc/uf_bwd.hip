@@ -409,11 +409,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_kernel(const T* __restri
         Raw araw[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) araw[r] = *reinterpret_cast<const Raw*>(a1b + (o00 + r * rowb));
-        float hc[R][N], acc[R][N];
+        float hc[R][N], dg[R][N], acc[R][N];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            CH::unpack(araw[r], hc[r]);
-            gelu_n<T, N>(hc[r]);
+            float av[N];
+            CH::unpack(araw[r], av);
+#pragma unroll
+            for (int i = 0; i < N; ++i) gelu_and_grad_t<T>(av[i], hc[r][i], dg[r][i]);      // one exp2 / rcp pair for both (uf_common.h)
             round_t<T, N>(hc[r]);
 #pragma unroll
             for (int i = 0; i < N; ++i) acc[r][i] = 0.f;
@@ -487,11 +489,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_kernel(const T* __restri
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float a[N];
-            CH::unpack(araw[r], a);
             round_t<T, N>(acc[r]);
 #pragma unroll
-            for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
+            for (int i = 0; i < N; ++i) acc[r][i] *= dg[r][i];
             *reinterpret_cast<Raw*>(dab + (o00 + r * rowb)) = CH::pack(acc[r]);
         }
     }
@@ -574,11 +574,13 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_walk_kernel(const T* __r
             Raw araw[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) araw[r] = *reinterpret_cast<const Raw*>(a1b + (ro[r + 1] + (unsigned)(dx * (int)pixb)));
-            float hc[R][N], acc[R][N];
+            float hc[R][N], dg[R][N], acc[R][N];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                CH::unpack(araw[r], hc[r]);
-                gelu_n<T, N>(hc[r]);
+                float av[N];
+                CH::unpack(araw[r], av);
+#pragma unroll
+                for (int i = 0; i < N; ++i) gelu_and_grad_t<T>(av[i], hc[r][i], dg[r][i]);  // one exp2 / rcp pair for both (uf_common.h)
                 round_t<T, N>(hc[r]);
 #pragma unroll
                 for (int i = 0; i < N; ++i) { acc[r][i] = 0.f; wacc[9][i] += cM[r + 1][i]; }
@@ -601,11 +603,9 @@ __global__ __launch_bounds__(256, 2) void dwconv3x3_bwd_walk_kernel(const T* __r
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                float a[N];
-                CH::unpack(araw[r], a);
                 round_t<T, N>(acc[r]);
 #pragma unroll
-                for (int i = 0; i < N; ++i) acc[r][i] *= gelu_grad_t<T>(a[i]);
+                for (int i = 0; i < N; ++i) acc[r][i] *= dg[r][i];
                 *reinterpret_cast<Raw*>(dab + (ro[r + 1] + (unsigned)(dx * (int)pixb))) = CH::pack(acc[r]);
             }
         };

@@ -150,6 +150,29 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float a) {
     }
 }
 
+// GELU(a) and GELU'(a) together (round 6: the fused depthwise backward needs both for every element -- h1 = GELU(a1) for the tap gradients, GELU'(a1) for
+// the input gradient).  2-byte operand types: ONE exp2 / rcp pair serves both (the two separate calls evaluated the same e = 2^u and 1 / (1 + e) twice: 4
+// quarter-rate instructions and 3 multiplies per element more).  dg is gelu_grad_t<T>(a) bit for bit; g is gelu_n's value for every a > -8.4 (below that the
+// clamp of u that keeps dg finite makes g = a 2^-80 instead of a / (1 + 2^u): both are zero to 23 decimal places).  Other types: the two calls.
+#ifndef UF_GELU_PAIR
+#define UF_GELU_PAIR 1      // 0: the two separate evaluations (A/B builds: scripts/build_variant.sh)
+#endif
+template <typename T> __device__ __forceinline__ void gelu_and_grad_t(float a, float& g, float& dg) {
+    if constexpr (GeluKind<T>::v == 1 && UF_GELU_PAIR) {
+        constexpr float A = -2.3022081985f, B = -0.10294324f;                 // as gelu_bf2
+        const float u = fminf(a * (a * a * B + A), 80.0f);
+        const float e = __builtin_amdgcn_exp2f(u);
+        const float sg = __builtin_amdgcn_rcpf(e + 1.0f);
+        g = a * sg;
+        dg = sg + a * e * sg * sg * (1.5957691216f + 0.2140610f * a * a);
+    } else {
+        float t[2] = {a, a};
+        gelu_n<T, 2>(t);
+        g = t[0];
+        dg = gelu_grad_t<T>(a);
+    }
+}
+
 template <typename T> __device__ __forceinline__ void gelu4(f32x4& v) {
     float t[4] = {v[0], v[1], v[2], v[3]};
     gelu_n<T, 4>(t);
