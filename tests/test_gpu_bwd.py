@@ -166,7 +166,7 @@ def test_dwconv_that_activates_its_input_equals_the_stencil_on_the_stored_activa
 def test_linear_wgrad_and_input_grad(dtype, M, N, K, monkeypatch):
     """dW = dY^T X, db = column sums (token-split MFMA kernel, two-stage sums) and dX = dY W through the forward GEMM."""
     from uformer_amd import ops
-    monkeypatch.setenv("UF_WGRAD_V4", "1")           # the 256 x 256-tile kernel on every shape it supports (by default only with >= 64 K tokens)
+    monkeypatch.setenv("UF_VARIANT", "wgrad4=1")           # the 256 x 256-tile kernel on every shape it supports (by default only with >= 64 K tokens)
     x = torch.randn(M, K, generator=g(10)).to(dtype)
     dy = torch.randn(M, N, generator=g(11)).to(dtype)
     w = (torch.randn(N, K, generator=g(12)) / K ** 0.5).to(dtype)
@@ -188,7 +188,7 @@ def test_linear_wgrad_never_reads_past_the_last_token(dtype, v4, M, N, K, monkey
     instruction's SCALAR offset and rely on the descriptor's bounds check to zero the rows past M in the last step.  Here M is not a multiple of 64 and
     the rows directly behind dY and X (same allocation) are NaN: a tail that were read would poison dW / db."""
     from uformer_amd import ops
-    monkeypatch.setenv("UF_WGRAD_V4", v4)
+    monkeypatch.setenv("UF_VARIANT", "wgrad4=" + v4)
     G = 192                                                       # guard rows behind the operands
     xb = torch.full((M + G, K), float("nan")).to(dtype).cuda()
     dyb = torch.full((M + G, N), float("nan")).to(dtype).cuda()
@@ -209,11 +209,11 @@ def test_linear_wgrad_tile_versions_agree(dtype, M, N, K, monkeypatch):
     from uformer_amd import _lib, ops
     x = torch.randn(M, K, generator=g(13)).to(dtype).cuda()
     dy = torch.randn(M, N, generator=g(14)).to(dtype).cuda()
-    monkeypatch.setenv("UF_WGRAD_V4", "1")
+    monkeypatch.setenv("UF_VARIANT", "wgrad4=1")
     dW4, db4 = ops.linear_wgrad(dy, x)
-    monkeypatch.setenv("UF_WGRAD_V4", "0")
+    monkeypatch.setenv("UF_VARIANT", "wgrad4=0")
     dW3, db3 = ops.linear_wgrad(dy, x)
-    monkeypatch.setenv("UF_WGRAD_V4", "1")
+    monkeypatch.setenv("UF_VARIANT", "wgrad4=1")
     assert rel(dW4, dW3.cpu()) < 2e-6 and rel(db4, db3.cpu()) < 2e-6
     assert not torch.equal(dW3, torch.zeros_like(dW3))
     # strided operands: columns [N/2, N/2 + 256) of dy as a 256-wide layer's output gradient

@@ -199,9 +199,9 @@ def test_gemm_dma_bit_identical(ops, dtype, M, N, K, monkeypatch):
             outs += list(ops.qkv(a, w, b, K // 32))
         return outs
 
-    monkeypatch.setenv("UF_GEMM_DMA", "0")
+    monkeypatch.setenv("UF_VARIANT", "gemm_dma=0")
     ref = run_all()
-    monkeypatch.setenv("UF_GEMM_DMA", "1")
+    monkeypatch.setenv("UF_VARIANT", "gemm_dma=1")
     got = run_all()
     torch.cuda.synchronize()
     for i, (g, r) in enumerate(zip(got, ref)):
@@ -394,11 +394,11 @@ for (B, H, C, heads) in ((2, 64, 32, 1), (1, 128, 128, 4), (2, 32, 64, 2), (5, 6
 print("HASHES " + " ".join(out))
 """ % root
     res = {}
-    for tag, env in (("default", {}), ("leff2 8 producers", {"UF_LEFF2_VARIANT": "p"}), ("leff2 never 8 producers", {"UF_LEFF2_VARIANT": "n"}),
-                     ("leff2 one tile per workgroup", {"UF_LEFF2_PERSIST": "0"}),
-                     ("leff2 tile walk everywhere", {"UF_LEFF2_PERSIST": "1"}), ("attn_block first form", {"UF_ATTN_LR": "0"}),
-                     ("attn_block low-register form", {"UF_ATTN_LR": "1"}), ("attn_block low-register code, first bounds", {"UF_ATTN_LR": "2"}),
-                     ("attn_block C = 256 two operand tiles", {"UF_ATTN_ST": "0"}), ("attn_block C = 256 single operand tile (O overwrites Xn)", {"UF_ATTN_ST": "1"})):
+    for tag, env in (("default", {}), ("leff2 8 producers", {"UF_VARIANT": "leff2=1"}), ("leff2 never 8 producers", {"UF_VARIANT": "leff2=2"}),
+                     ("leff2 one tile per workgroup", {"UF_VARIANT": "persist=0"}),
+                     ("leff2 tile walk everywhere", {"UF_VARIANT": "persist=1,leff2=2"}), ("attn_block first form", {"UF_VARIANT": "attn=0"}),
+                     ("attn_block low-register form", {"UF_VARIANT": "attn=1"}), ("attn_block low-register code, first bounds", {"UF_VARIANT": "attn=2"}),
+                     ("attn_block C = 256 single operand tile (O overwrites Xn)", {"UF_VARIANT": "attn=3"})):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         line = [l for l in r.stdout.splitlines() if l.startswith("HASHES ")]
         assert r.returncode == 0 and line, (tag, r.stdout[-1500:], r.stderr[-1500:])
@@ -431,9 +431,9 @@ def test_stem_beside_mfma_kernels_of_another_stream(ops, monkeypatch):
     img = torch.rand(B, 3, H, H, device="cuda")
     w27 = (torch.randn(27, E, device="cuda") * 0.2).contiguous()
     bias = (torch.randn(E, device="cuda") * 0.1).contiguous()
-    monkeypatch.setenv("UF_INPUT_PROJ_V2", "0")
+    monkeypatch.setenv("UF_VARIANT", "stem=1")
     ref = ops.input_proj(img, w27, bias)
-    monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")
+    monkeypatch.setenv("UF_VARIANT", "stem=2")
     side = torch.cuda.Stream()
     ga = torch.randn(131072, 256, device="cuda").to(torch.bfloat16)
     gw = torch.randn(1024, 256, device="cuda").to(torch.bfloat16)
@@ -469,9 +469,9 @@ def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
         bias = torch.randn(E, generator=gen) * 0.1
         from uformer_amd import packing
         w27 = packing.pack_input_proj(w).cuda()
-        monkeypatch.setenv("UF_INPUT_PROJ_V2", "0")
+        monkeypatch.setenv("UF_VARIANT", "stem=1")
         ref = ops.input_proj(img, w27, bias.cuda())
-        monkeypatch.setenv("UF_INPUT_PROJ_V2", "1")                   # the default form
+        monkeypatch.setenv("UF_VARIANT", "stem=2")                   # the default form
         got = ops.input_proj(img, w27, bias.cuda())
         assert torch.equal(got, ref), f"input_proj E={E}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
         ora = O.input_proj(img.cpu(), {"input_proj.proj.0.weight": w, "input_proj.proj.0.bias": bias})
@@ -483,9 +483,9 @@ def test_stem_head_lds_forms_bit_identical(ops, B, H, W, monkeypatch):
         from uformer_amd import packing
         wp = packing.pack_output_proj(w).cuda()
         for add in (None, img):
-            monkeypatch.setenv("UF_OUTPUT_PROJ_V1", "1")
+            monkeypatch.setenv("UF_VARIANT", "head=1")
             ref = ops.output_proj(x, wp, bias.cuda(), B, H, W, add)
-            monkeypatch.setenv("UF_OUTPUT_PROJ_V1", "0")
+            monkeypatch.setenv("UF_VARIANT", "head=2")
             got = ops.output_proj(x, wp, bias.cuda(), B, H, W, add)
             assert torch.equal(got, ref), f"output_proj C2={C2}: LDS form differs, max abs {(got - ref).abs().max().item():.3e}"
         ora = torch.nn.functional.conv2d(x.cpu().reshape(B, H, W, C2).permute(0, 3, 1, 2), w, bias, stride=1, padding=1) + img.cpu()    # OutputProj + global residual (model.py:828-836, :1305)

@@ -102,9 +102,6 @@ constexpr float LOG2E = 1.4426950408889634f;
 #endif
 template <int C> constexpr bool hoist_on() { return (C <= 128 && (UF_HOIST & 1)) || (C == 256 && (UF_HOIST & 2)) || (C == 512 && (UF_HOIST & 4)); }
 
-#ifndef UF_ATTN_ST_DEFAULT
-#define UF_ATTN_ST_DEFAULT false
-#endif
 #ifndef UF_ATTN_LR_DEFAULT
 #define UF_ATTN_LR_DEFAULT 0
 #endif
@@ -925,7 +922,8 @@ int launch_one(const AttnBlkParams& p, hipStream_t st) {
     const double M = (double)p.n_windows * 64;
     const double fc1_flops = p.h1 ? 2.0 * M * C * 4.0 * C : 0.0, fc1_bytes = p.h1 ? M * 4.0 * C * sizeof(T) + 4.0 * C * C * sizeof(T) : 0.0;
     {
-        ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0) + fc1_flops, M * C * 8.0 + 4.0 * C * C * sizeof(T) + fc1_bytes, st);
+        const double side_bytes = TR ? 6.0 * M * C * sizeof(T) : 0.0;     // training form: xn, q, k, v^T, o, z stored beside x1 and a1
+        ScopedTimer tm(name, 2.0 * M * C * (4.0 * C + 128.0) + fc1_flops, M * C * 8.0 + 4.0 * C * C * sizeof(T) + fc1_bytes + side_bytes, st);
         hipLaunchKernelGGL(kern, dim3(p.n_windows), dim3(NT), smem, st, p);
     }
     return check_launch("attn_block");
@@ -963,17 +961,16 @@ int launch_attn_block(const uf_block_params* bp, float* x, int ld, int B, int H,
     p.qscale = (float)(1.0 / sqrt(32.0)) * LOG2E;   // q = q * scale (model.py:497), times log2(e): softmax via exp2
     p.tbuf = debug_get_tbuf();
 
-    // low-register form at C <= 128 (see attn_block_kernel): UF_ATTN_LR=1 with the tighter register bound (one more workgroup per CU),
-    // =2 the same code at the occupancy of the first form, =0 the first form (A/B runs)
-    // Default by shape, from the same-box A/B of the three bit-identical forms (profiles/r04_run4.txt, ms per step: first / LR=1 / LR=2):
-    // C = 32 (enc0) 0.187 / 0.212 / 0.172 -> LR=2; C = 128 with >= 4096 windows (dec2) 0.409 / 0.383 / 0.406 -> LR=1; everything else stays
+    // Form by shape; UF_VARIANT="attn=k" forces one (A/B runs, bit-identity test): 0 the first form, 1 the low-register form at C <= 128 with the tighter
+    // register bound (one more workgroup per CU), 2 the same code at the occupancy of the first form, 3 the single-operand-tile form at C = 256.
+    // Defaults from the same-box A/B of the bit-identical forms (profiles/r04_run4.txt, ms per step: first / 1 / 2):
+    // C = 32 (enc0) 0.187 / 0.212 / 0.172 -> 2; C = 128 with >= 4096 windows (dec2) 0.409 / 0.383 / 0.406 -> 1; everything else stays
     // on the first form (C = 128 with 1024 windows 0.445 / 0.445 / 0.467, C = 64 0.361 / 0.373 / 0.366 and 0.177 / 0.179 / 0.183).
-    static const char* elr = getenv("UF_ATTN_LR");
-    const int lr = elr ? atoi(elr) : (C == 32 ? 2 : ((C == 128 && p.n_windows >= 4096) ? 1 : 0));
-    // C = 256 with more windows than one round of workgroups (dec1 at batch >= 8): the single-operand-tile form (LR = 3), three workgroups per CU.
-    // UF_ATTN_ST=0 / 1 forces the two-tile / single-tile form (A/B runs; bit-identical results)
-    static const char* est = getenv("UF_ATTN_ST");
-    const bool st256 = est ? est[0] == '1' : UF_ATTN_ST_DEFAULT;
+    // The single-tile form (3) is NOT a default: bit-identical, three workgroups per CU, 128 vs 136 us on the isolated dec1 launch but 123 vs 117 us
+    // inside the model and the MFMA pipe busy 26.5 % instead of 27.7 % (profiles/r06_run3_stages.txt, r06_run4_ab.txt, r06_pmc?_st?_attn_leff.csv).
+    const int forced = variant("attn", -1);
+    const int lr = (forced >= 0 && forced <= 2) ? forced : (forced == 3 ? 0 : (C == 32 ? 2 : ((C == 128 && p.n_windows >= 4096) ? 1 : 0)));
+    const bool st256 = forced == 3;
 #define UF_AB(TT, CV, NTV) return launch_one<TT, CV, NTV>(p, st)
 #define UF_AB_HALF(TT)                                                                                                              \
         switch (C) {                                                                                                                    \

@@ -1927,11 +1927,11 @@ static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
 // Uformer-B shapes at batch 32 (profiles/r04_run12.txt, microseconds third / fourth): 131072 x 1024 x 256: 105 / 90, 131072 x 768 x 256: 125 / 121,
 // 131072 x 256 x 256: 35 / 45, 32768 x 2048 x 512: 82 / 83, 32768 x 1024 x 256: 34 / 41, 8192 x 2048 x 512: 33 / 43 -- it pays with many tokens per
 // chunk (its pipeline is three stages deep before the first MFMA, and a chunk's partial tile is four times as large), so that is where it runs.
-// UF_WGRAD_V4=0 turns it off, UF_WGRAD_V4=1 runs it on every shape it supports (A/B runs, tests).
+// UF_VARIANT="wgrad4=0" turns it off, "wgrad4=1" runs it on every shape it supports (A/B runs, tests).
 static bool wgrad4_shape(int M, int N, int K) {
-    const char* e = getenv("UF_WGRAD_V4");
-    if ((e && e[0] == '0') || !wgrad_v2() || N % 256 || K % 256 || M < 256) return false;
-    if (e && e[0] == '1') return true;
+    const int e = variant("wgrad4", -1);
+    if (e == 0 || !wgrad_v2() || N % 256 || K % 256 || M < 256) return false;
+    if (e == 1) return true;
     return M >= 65536 && (long long)N * K >= 196608;
 }
 static int wgrad4_chunks(int M, int N, int K) {

@@ -382,6 +382,7 @@ __device__ __forceinline__ int window_token(const WinGeom& g, int t) {   // t = 
 // host side: error reporting
 // ------------------------------------------------------------------------------------
 void set_error(const char* fmt, ...);
+int variant(const char* key, int dflt);   // UF_VARIANT="key=value,...": launch-variant selector for A/B runs and bit-identity tests (uf_core.hip)
 int check_launch(const char* what);
 
 // Opt-in timing (uf_timing_enable): brackets one kernel launch with HIP events on its stream and

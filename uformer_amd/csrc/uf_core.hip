@@ -5,11 +5,35 @@
 #include <string>
 #include <vector>
 
+#include <stdlib.h>
+#include <string.h>
+
 #include "uf_internal.h"
 
 namespace uf {
 
 static thread_local char g_err[512] = "";
+
+// UF_VARIANT="key=value,key=value,...": the ONE environment variable that selects between launch variants of a kernel for A/B runs and for the
+// bit-identity tests (round 6: it replaces eight separate UF_* switches).  Every variant of a key computes identical bits; without the key the shape picks.
+//   attn=0|1|2|3    attn_block: first form / low-register form with tight / relaxed register bounds / single-operand-tile form (C = 256)
+//   leff2=1|2       leff2: 8 producer waves wherever they are built / never
+//   persist=0|1     leff2: one tile per workgroup / the persistent tile walk everywhere
+//   gemm_dma=0|1    gemm_kernel: register-staged / LDS-DMA operand staging on every shape that supports it
+//   wgrad4=0|1      linear_wgrad4 (256 x 256 tiles) never / on every shape it supports
+//   stem=1, head=1  the first (global-load) forms of input_proj / output_proj instead of the LDS-staged ones
+// Read per call (a getenv and a scan of a short string beside a kernel launch): the tests flip keys inside one process.  Returns `dflt` without the key.
+int variant(const char* key, int dflt) {
+    const char* e = getenv("UF_VARIANT");
+    if (!e) return dflt;
+    const size_t n = strlen(key);
+    for (const char* q = e; *q;) {
+        if (!strncmp(q, key, n) && q[n] == '=') return atoi(q + n + 1);
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+    }
+    return dflt;
+}
 
 void set_error(const char* fmt, ...) {
     va_list ap;

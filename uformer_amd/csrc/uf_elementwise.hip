@@ -831,9 +831,8 @@ extern "C" int uf_input_proj_fwd(const float* img, const float* w27, const float
     const unsigned nx = (unsigned)((W + px - 1) / px) * (unsigned)(E / 4);
     ScopedTimer tm("input_proj", 18.0 * B * H * W * Cin * E, 4.0 * B * H * W * (Cin + E), (hipStream_t)stream);
     // The LDS-staged second form (input_proj2_kernel: 107 -> 44 us at 16 x 256 x 256, bit-identical to the first form) is the default since the
-    // packed-f32 operand-select hazard that corrupted it beside MFMA kernels was found and removed (see the kernel comment); UF_INPUT_PROJ_V2=0: first form.
-    const char* e2 = getenv("UF_INPUT_PROJ_V2");
-    const bool v1 = e2 && e2[0] == '0';
+    // packed-f32 operand-select hazard that corrupted it beside MFMA kernels was found and removed (see the kernel comment); UF_VARIANT="stem=1": first form.
+    const bool v1 = variant("stem", 2) == 1;
     if (!v1 && Cin == 3 && (E == 32 || E == 16) && (H + 3) / 4 <= 65535) {
         const dim3 g32 = (UF_IP2_DBG & 16) ? dim3(((W + 63) / 64) * ((H + 3) / 4) * B) : dim3((W + 63) / 64, (H + 3) / 4, B);
         const dim3 g16 = (UF_IP2_DBG & 16) ? dim3(((W + 127) / 128) * ((H + 3) / 4) * B) : dim3((W + 127) / 128, (H + 3) / 4, B);
@@ -855,9 +854,8 @@ extern "C" int uf_output_proj_fwd(const float* x, int ld_x, const float* w, cons
     hipStream_t st = (hipStream_t)stream;
     const long long pix = (long long)B * H * W;
     ScopedTimer tm("output_proj", 54.0 * pix * C2, 4.0 * pix * (C2 + 6), st);
-    {   // second form (LDS-DMA staged halo tile) where the tile fits LDS and 32-bit byte offsets address the tensor; UF_OUTPUT_PROJ_V1=1: first form
-        const char* e1 = getenv("UF_OUTPUT_PROJ_V1");
-        const bool v1 = e1 && e1[0] != '0';
+    {   // second form (LDS-DMA staged halo tile) where the tile fits LDS and 32-bit byte offsets address the tensor; UF_VARIANT="head=1": first form
+        const bool v1 = variant("head", 2) == 1;
         if (!v1 && (C2 == 16 || C2 == 32 || C2 == 64) && (long long)B * H * W * ld_x * 4 < 0xffffff00LL) {
             const int lpp = C2 / 4, tw = 2 * (256 / lpp), tiles_x = (W + tw - 1) / tw, tiles_y = (H + OP_R - 1) / OP_R;
             const int smem = (6 * (tw + 2) * C2 * 4 + 1023) / 1024 * 1024;      // whole DMA instructions (1 KiB each): the last one may run past the tile

@@ -492,15 +492,15 @@ int launch_kern(const GemmParams& p, hipStream_t stream) {
 // 712 -> 882, dxn 788 -> 975, qkv 656 -> 712, dO 627 -> 703; dz / dxn of dec1 666 -> 701 / 680 -> 784) and the wide K = 256 products
 // (linear1 of dec1, N = 4 K: 340 -> 383) gain; the narrow K <= 256 ones (dO 510 -> 475 at C = 256, qkv 304 -> 290 at C = 128) lose a
 // little: with 2-4 K tiles the second workgroup of a CU hides the staging stores as well as the DMA does, and the DMA path's prologue
-// waits for its first tile with nothing else in flight.  UF_GEMM_DMA=0 / =1 force the register / DMA path wherever it applies
+// waits for its first tile with nothing else in flight.  UF_VARIANT="gemm_dma=0" / "gemm_dma=1" force the register / DMA path wherever it applies
 // (A/B runs, bit-identity test).
 template <typename T, int BN, int WGM, int WGN, int AL, int EP>
 int launch_cfg(const GemmParams& p, hipStream_t stream) {
     if constexpr (sizeof(T) == 2 && AL == A_PLAIN) {
-        const char* e = getenv("UF_GEMM_DMA");      // read per call: the bit-identity test flips it inside one process
+        const int e = variant("gemm_dma", -1);      // UF_VARIANT="gemm_dma=0|1", read per call: the bit-identity test flips it inside one process
         const bool can = p.K % 64 == 0 && p.K >= 128 && (long long)p.M * p.lda * 2 < 0xffffff00LL && (long long)p.N * p.K * 2 < 0xffffff00LL;
         const bool pays = p.K >= 512 || (p.K >= 256 && p.N >= 4 * p.K);
-        const bool on = e ? e[0] != '0' : pays;
+        const bool on = e >= 0 ? e != 0 : pays;
         if (can && on) return launch_kern<T, BN, WGM, WGN, AL, EP, true>(p, stream);
     }
     return launch_kern<T, BN, WGM, WGN, AL, EP, false>(p, stream);

@@ -409,10 +409,10 @@ int launch_v(const Leff2Params& p, hipStream_t st) {
         // workgroup (profiles/r04_run6.txt, ms per step): C = 32 0.163 -> 0.129, C = 256 (dec1) 0.653 -> 0.621, C = 128 with 1024 tiles 0.339 -> 0.329,
         // but C = 64 0.263 -> 0.267 / 0.137 -> 0.137 and C = 128 with 4096 tiles 0.308 -> 0.332 (three workgroups per CU already cover each other's
         // prologue and epilogue there, and an even split leaves 688 of 768 slots filled) -- so the walk is used where it paid.
-        // UF_LEFF2_PERSIST=0 / =1: never / wherever there are more tiles than resident workgroups.
-        static const char* pe = getenv("UF_LEFF2_PERSIST");
+        // UF_VARIANT="persist=0" / "persist=1": never / wherever there are more tiles than resident workgroups.
+        const int pe = variant("persist", -1);
         const bool pays = C <= 32 || C >= 256 || (C == 128 && p.n_tiles <= 1024);
-        const bool persist = pe ? pe[0] != '0' : pays;
+        const bool persist = pe >= 0 ? pe != 0 : pays;
         constexpr int waves = PW * NPG + NC;
         constexpr int by_lds = (160 * 1024) / smem, by_waves = 32 / waves, by_regs = (WPS * 4) / waves > 0 ? (WPS * 4) / waves : 1;
         constexpr int per_cu = by_lds < by_waves ? (by_lds < by_regs ? by_lds : by_regs) : (by_waves < by_regs ? by_waves : by_regs);
@@ -456,9 +456,9 @@ int launch_c(const Leff2Params& p, hipStream_t st) {
         // is a serial chain of LDS round trips (taps -> fragments -> halo reads -> MFMA -> GELU -> operand tile: ~2 K cycles per interval
         // for ~250 instructions, scripts/ubench.py stamps2), so with nothing else resident on the CU shorter chains win -- enc2 (C = 128,
         // 1024 tiles) 0.322 -> 0.307 ms per step, enc3 (C = 256, 256 tiles) 0.247 -> 0.234; with several rounds of workgroups the wider
-        // workgroups cost residency (dec1 0.631 -> 0.739, C <= 64 +4...9 %): profiles/r04_run2.txt.  UF_LEFF2_VARIANT=p forces it, =n never.
-        static const char* ev = getenv("UF_LEFF2_VARIANT");
-        const bool force = ev && ev[0] == 'p', never = ev && ev[0] == 'n';
+        // workgroups cost residency (dec1 0.631 -> 0.739, C <= 64 +4...9 %): profiles/r04_run2.txt.  UF_VARIANT="leff2=1" forces it, "leff2=2" never.
+        const int ev = variant("leff2", 0);
+        const bool force = ev == 1, never = ev == 2;
         // (Stencil jobs on the consumer waves -- template parameter CP -- measured -8 % in round 4, profiles/r04_run7.txt, and are not instantiated.)
         if constexpr (C == 128) { if (!never && (force || tiles <= 1024)) return launch_v<T, C, 1, 4, 2, 6, 8>(p, st); }
         else if constexpr (C == 256) { if (!never && (force || tiles <= 256 || UF_L256_BIG)) return launch_v<T, C, 1, 8, UF_NB256E, 4, 8>(p, st); }

@@ -215,6 +215,8 @@ def fused_attn_covers(T: torch.dtype, C: int, heads: int) -> bool:
 # module attributes, not environment switches (round 5): the shipped forms; the alternatives stay reachable for tests / A-B runs by setting the attribute
 _GELU_IN = True            # False: linear1 writes pre-activation AND activation, the stencil reads the latter
 _DW_BWD_FUSED = True       # False: the two-kernel depthwise backward (uf_dwconv3x3_mul_dgelu + uf_dwconv3x3_wgrad)
+_VERBOSE = False           # True: say which training form (kept-intermediates / recompute) was chosen and why
+_NATIVE_PACK = True        # False: per-step operand packing through ATen (BlockPack) instead of uf_pack_block_train
 
 
 class _Side:
@@ -405,7 +407,7 @@ def choose_recompute(cfg, B: int, H: int, device) -> bool:
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
             choice = bool(flag.item() > 0)
         _RECOMPUTE_CHOICE[key] = choice
-        if os.environ.get("UF_TRAIN_VERBOSE"):
+        if _VERBOSE:
             print(f"[uformer_amd.train] batch {B} at {H}x{H}: {'recompute' if choice else 'kept-intermediates'} form ({need / 1e9:.1f} GB of intermediates, {free / 1e9:.1f} GB available)", flush=True)
     return _RECOMPUTE_CHOICE[key]
 
@@ -464,7 +466,7 @@ class UformerTape:
                 # utils/model_utils.py:66-67) takes the op-by-op forward that keeps its intermediates and the op-level backward
                 fusable = self.recompute and C == 32 * cfg.num_heads[s]
                 # uf_pack_block_train (5 launches) covers C % 32 == 0; its pack also serves the op-by-op form as tensor views
-                native = C % 32 == 0 and C % cfg.num_heads[s] == 0 and os.environ.get("UF_PY_PACK") is None      # UF_PY_PACK=1: the ATen packing (tests, A/B)
+                native = C % 32 == 0 and C % cfg.num_heads[s] == 0 and _NATIVE_PACK
                 pk = self.packs[prefix] = (NativeBlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T) if native else
                                            BlockPack(sd, prefix, cfg.num_heads[s], shifts[s][i], T, fused=fusable or fused_attn_covers(T, C, cfg.num_heads[s])))
                 if fusable:                                                     # fused kernels; the block's input is all that is kept
