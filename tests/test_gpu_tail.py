@@ -280,3 +280,55 @@ def test_restore_tiled_matches_single_tile_and_tracks_full_frame():
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump({"psnr_tiled_vs_full_db": ps}, open("gpurun_out/parity_tiled.json", "w"))
     assert ps >= 30.0, ps
+
+
+def _sink_on_gpu_worker(rank, world, port, q, algorithm, payload):
+    """two ranks SHARE cuda:0 and meet over gloo (what a 1-GPU box allows): buckets of device tensors, the exchange chained on the sink's side stream
+    behind the kernels that wrote them, AdamW's grad_scale path afterwards -- the stream plumbing of uformer_amd.dist on real hardware"""
+    import sys
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from uformer_amd import dist as ud
+    ud.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    g = torch.Generator().manual_seed(7)
+    shapes = [(512, 2048), (2048,), (300, 300), (64, 512), (1000,), (257, 129)]
+    params = [(f"p{i}", torch.nn.Parameter(torch.zeros(s, device=dev))) for i, s in enumerate(shapes)]
+    sink = ud.OverlappedGradientAllReduce(params, bucket_bytes=1 << 20, algorithm=algorithm, payload=getattr(torch, payload))
+    worst = 0.0
+    for step in range(3):
+        local = {n: torch.randn(p.shape, generator=g) * (1 + rank) for n, p in params}           # both ranks draw the same stream: rank r holds (1 + r) x
+        sink.begin_step()
+        for n, p in reversed(params):
+            t = local[n].to(dev)
+            big = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)       # work in flight on the compute stream when the bucket is launched
+            sink.deliver({n: t * 1.0})
+            del big
+        sink.finish()
+        for n, p in params:
+            want = local[n] * (sum(1 + r for r in range(world)) / (1 + rank))                     # sum over ranks of (1 + r) x
+            got = p.grad.detach().float().cpu()
+            worst = max(worst, float((got - want).abs().max() / want.abs().max()))
+    q.put((rank, worst))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algorithm,payload,tol", [("ring", "float32", 1e-6), ("direct", "float32", 1e-6), ("direct", "bfloat16", 1.2e-2)])
+def test_gradient_sink_on_device_tensors_two_ranks_one_gpu(algorithm, payload, tol):
+    """uformer_amd.dist.OverlappedGradientAllReduce with DEVICE buckets (gloo, two ranks sharing the GPU): the all-reduce and the direct exchange (round 6: its
+    side stream, the staging buffers, the join in finish()) give the sum over ranks while the compute stream is busy, three steps in a row."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sink_on_gpu_worker, args=(r, 2, port, q, algorithm, payload)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(w < tol for _, w in res), res
