@@ -47,6 +47,15 @@ struct SmallPack {
     int C, heads;
 };
 
+// The depthwise taps are ROUNDED TO THE OPERAND TYPE here (round 6): the fused inference kernel evaluates the stencil on the matrix pipe with
+// taps of the operand type (uf_leff2.hip, UF_MCONV = 1) while the op-level training kernels took the f32 taps -- eval and train forwards of the same weights
+// differed in tap precision, and in the recompute form the loss came from one function and its gradient from another.  With the pack rounding them, every
+// training kernel (forward stencil, input gradient with the flipped taps) and the fused forward see the same values; the tap GRADIENT stays f32 (straight through).
+template <typename T> __device__ __forceinline__ float round_tap(float w) {
+    if constexpr (sizeof(T) == 2) { T t; store1(&t, w); return load1(&t); }
+    else return w;
+}
+template <typename T>
 __device__ __forceinline__ void pack_small_items(const SmallPack& p, int first, int stride) {
     const int C = p.C, C4 = 4 * C;
     const int n_b = 3 * C, n_w = 9 * C4, n_d = p.heads * 4096, n_t = p.heads * 225;
@@ -54,9 +63,9 @@ __device__ __forceinline__ void pack_small_items(const SmallPack& p, int first, 
         int j = i;
         if (j < n_b) { p.bqkv[j] = j < C ? p.qb[j] : p.kvb[j - C]; continue; }
         j -= n_b;
-        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9[j] = p.dw[c * 9 + t]; continue; }
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9[j] = round_tap<T>(p.dw[c * 9 + t]); continue; }
         j -= n_w;
-        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9_flip[j] = p.dw[c * 9 + 8 - t]; continue; }
+        if (j < n_w) { const int t = j / C4, c = j - t * C4; p.w9_flip[j] = round_tap<T>(p.dw[c * 9 + 8 - t]); continue; }
         j -= n_w;
         if (j < n_d) { const int h = j >> 12, qk = j & 4095; p.dense[j] = p.table[(size_t)p.index[qk] * p.heads + h]; continue; }
         j -= n_d;
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(256) void pack_block_kernel(const BlockPackJobs j) 
     else if (b < j.e[1]) pack_linear_block<T>(j.m[1], b - j.e[0]);
     else if (b < j.e[2]) pack_linear_block<T>(j.m[2], b - j.e[1]);
     else if (b < j.e[3]) pack_linear_block<T>(j.m[3], b - j.e[2]);
-    else pack_small_items(j.sp, (b - j.e[3]) * 256 + threadIdx.x, j.n_small_blocks * 256);
+    else pack_small_items<T>(j.sp, (b - j.e[3]) * 256 + threadIdx.x, j.n_small_blocks * 256);
 }
 
 struct PackPlan {

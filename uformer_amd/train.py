@@ -60,6 +60,8 @@ class BlockPack:
         self.wp, self.w1, self.w2 = f("attn.proj.weight").to(T), f("mlp.linear1.0.weight").to(T), f("mlp.linear2.0.weight").to(T)
         self.wqkv_t, self.wp_t, self.w1_t, self.w2_t = (w.t().contiguous() for w in (self.wqkv, self.wp, self.w1, self.w2))
         self.w9 = packing.pack_dwconv(f("mlp.dwconv.0.weight"))
+        if T in (torch.bfloat16, torch.float16):
+            self.w9 = self.w9.to(T).float()          # taps rounded to the operand type, as the fused forward's matrix-pipe stencil and uf_pack_block_train do (round 6)
         self.w9_flip = self.w9.flip(0).contiguous()
         self.bias = packing.rpb_dense(f("attn.relative_position_bias_table"), f("attn.relative_position_index"))
         self.p = p
