@@ -152,11 +152,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
     }
-    float* out = partial + (size_t)(blockIdx.x * RPB + rl) * 2 * C;
+    // the RPB row lanes of the workgroup meet in LDS and are added in lane order: ONE partial row per workgroup (round 6; there were RPB of them, which is
+    // what kept the grid at 512 workgroups = 2 waves per SIMD of a kernel that is a pure stream: with 2048 it holds 8 and four times the bytes in flight)
+    __shared__ float red[RPB][2 * C];
 #pragma unroll
     for (int i = 0; i < V4; ++i) {
-        *reinterpret_cast<f32x4*>(out + (i * LPR + sub) * 4) = adg[i];
-        *reinterpret_cast<f32x4*>(out + C + (i * LPR + sub) * 4) = adb[i];
+        *reinterpret_cast<f32x4*>(&red[rl][(i * LPR + sub) * 4]) = adg[i];
+        *reinterpret_cast<f32x4*>(&red[rl][C + (i * LPR + sub) * 4]) = adb[i];
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * 2 * C;
+    for (int j = threadIdx.x; j < 2 * C; j += 256) {
+        float t = red[0][j];
+#pragma unroll
+        for (int r = 1; r < RPB; ++r) t += red[r][j];
+        out[j] = t;
     }
 }
 
@@ -255,7 +265,7 @@ static inline void launch_column_sum2(hipStream_t st, const float* p1, int P1, s
 }
 constexpr int COLSUM_COLS = 32;   // columns per workgroup of column_sum_kernel
 
-constexpr int LN_BWD_MAX_BLOCKS = 512;
+constexpr int LN_BWD_MAX_BLOCKS = 2048;   // 8 workgroups per CU (62 registers: 8 waves per SIMD)
 
 // ---------------------------------------------------------------------------------------------------------------
 // depthwise 3x3 weight gradient: dw[t][c] = sum_{b,y,x} dc[b,y,x,c] * h[b, y+ky-1, x+kx-1, c],  db[c] = sum dc.
@@ -1727,7 +1737,8 @@ extern "C" int uf_gelu_fwd(const void* a, void* y, long long n, uf_dtype dtype, 
 extern "C" size_t uf_layernorm_bwd_workspace_bytes(int rows, int C) {
     if (rows <= 0 || C < 16) return 0;
     const int LPR = (C / 4) < 64 ? (C / 4) : 64;
-    return (size_t)LN_BWD_MAX_BLOCKS * (256 / LPR) * 2 * C * sizeof(float);
+    (void)LPR;
+    return (size_t)LN_BWD_MAX_BLOCKS * 2 * C * sizeof(float);
 }
 
 struct LnCastArgs { void* out; const float* scale; int mode, hw, H, W, shift; };
@@ -1748,7 +1759,7 @@ static int layernorm_bwd_any(const char* fn, const float* x, int ld_x, const flo
     case CV: {                                                                                                                \
         constexpr int LPR = (CV / 4) < 64 ? (CV / 4) : 64, RPB = 256 / LPR;                                                   \
         const int nblk = (rows + RPB - 1) / RPB, grid = nblk < LN_BWD_MAX_BLOCKS ? nblk : LN_BWD_MAX_BLOCKS;                  \
-        slots = grid * RPB;                                                                                                   \
+        slots = grid;                                                                                                         \
         if (f32dy) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, float>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const float*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift, \
                                       (LnCast<float>{(float*)ca.out, ca.scale, ca.mode, ca.hw, ca.H, ca.W, ca.shift})); \
         else if (dtype == UF_F16) hipLaunchKernelGGL((layernorm_bwd_kernel<CV, f16>), dim3(grid), dim3(256), 0, st, x, ld_x, gamma, (const f16*)dy, ld_dy, add, dx, ld_dx, partial, rows, win_h, win_w, shift, \
