@@ -59,12 +59,14 @@ __global__ __launch_bounds__(RB) void charbonnier_kernel(const float* __restrict
     const double t = block_sum(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
-__global__ void finalize_mean_kernel(const double* __restrict__ partial, int nb, double inv_n, float* __restrict__ out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < nb; ++i) t += partial[i];
-        out[0] = (float)(t * inv_n);
-    }
+// one workgroup of RB threads: thread t adds partials t, t + RB, ... in index order, block_sum adds the threads in a fixed order (bit-reproducible).  Round 6: it was
+// ONE thread walking all partials -- 124 us of dependent loads between the forward and the backward of every training step (profiles/r06_train_serial_kernel_stats.csv)
+__global__ __launch_bounds__(RB) void finalize_mean_kernel(const double* __restrict__ partial, int nb, double inv_n, float* __restrict__ out) {
+    __shared__ double sh[RB / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nb; i += RB) acc += partial[i];
+    const double t = block_sum(acc, sh);
+    if (threadIdx.x == 0) out[0] = (float)(t * inv_n);
 }
 
 // ---- multi-tensor AdamW ---------------------------------------------------------------------------------------------
@@ -311,7 +313,7 @@ extern "C" int uf_charbonnier_fwd_bwd(const float* y, const float* target, float
         ScopedTimer tm("charbonnier", 6.0 * n, (dy ? 12.0 : 8.0) * n, st);
         hipLaunchKernelGGL(charbonnier_kernel, dim3(nb), dim3(RB), 0, st, y, target, dy, (double*)ws, n / 4, n, eps * eps, grad_scale / (float)n);
     }
-    hipLaunchKernelGGL(finalize_mean_kernel, dim3(1), dim3(64), 0, st, (const double*)ws, nb, 1.0 / (double)n, loss);
+    hipLaunchKernelGGL(finalize_mean_kernel, dim3(1), dim3(RB), 0, st, (const double*)ws, nb, 1.0 / (double)n, loss);
     return check_launch("charbonnier");
 }
 
