@@ -1931,6 +1931,11 @@ static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     int S = target / tiles;
     if (S > steps) S = steps;
     if (S > 256) S = 256;
+    // XCD x owns chunks x, x + 8, ... (the launch rounds the chunk count up to a multiple of 8 and the surplus workgroups exit): with S % 8 != 0 the first S % 8
+    // XCDs carry one chunk = `tiles` workgroups more than the others and -- whenever that pushes them past their 64 resident workgroups -- run a second, nearly
+    // empty round while six XCDs idle.  Round 6: the q|k|v gradient (N = 3C: 12 tiles x 42 chunks = 72 workgroups on XCDs 0 and 1, 60 on the rest) took 125 us
+    // where linear1 (N = 4C: 16 x 32 = 64 everywhere) took 93 us for 4/3 of the work (profiles/r06_run12_wgrad.txt).  Whole multiples of 8 only.
+    if (S >= 8) S = S / 8 * 8;
     return S < 1 ? 1 : S;
 }
 
@@ -1950,6 +1955,7 @@ static int wgrad4_chunks(int M, int N, int K) {
     int S = 256 / tiles;     // one workgroup per CU (128 KiB of LDS each)
     if (S > steps / 4) S = steps / 4;                         // at least four stages per chunk
     if (S > 256) S = 256;
+    if (S >= 8) S = S / 8 * 8;                                // the same number of chunks on every XCD (see wgrad_chunks): 3 tiles x 85 chunks put 33 workgroups on five XCDs of 32 CUs
     return S < 1 ? 1 : S;
 }
 
