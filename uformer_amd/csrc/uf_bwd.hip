@@ -1930,7 +1930,7 @@ static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     const int target = T == 128 ? 512 : 2048;   // 512 vs 1024 vs 2048 measured: 148.8 / 151.0 / 151.1 ms per training step
     int S = target / tiles;
     if (S > steps) S = steps;
-    if (S > 256) S = 256;
+    if (S > 512) S = 512;       // one-tile shapes (C = 32: every weight; C = 64: the projection) had 256 workgroups for 512 slots under the old cap of 256
     // XCD x owns chunks x, x + 8, ... (the launch rounds the chunk count up to a multiple of 8 and the surplus workgroups exit): with S % 8 != 0 the first S % 8
     // XCDs carry one chunk = `tiles` workgroups more than the others and -- whenever that pushes them past their 64 resident workgroups -- run a second, nearly
     // empty round while six XCDs idle.  Round 6: the q|k|v gradient (N = 3C: 12 tiles x 42 chunks = 72 workgroups on XCDs 0 and 1, 60 on the rest) took 125 us
