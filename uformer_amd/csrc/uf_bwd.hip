@@ -1473,7 +1473,7 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
                                                                const float* __restrict__ bias_dense, const float* __restrict__ mask, int n_mask,
                                                                const T* __restrict__ dO, int ldo, T* __restrict__ dq, T* __restrict__ dk,
                                                                T* __restrict__ dvt, T* __restrict__ dqkv, float qscale, float* __restrict__ ws_bias, int n_windows,
-                                                               int heads, int H, int W, int shift) {
+                                                               int heads, int H, int W, int shift, int pair) {
     static_assert(sizeof(T) == 2 && (HD == 16 || HD == 32), "2-byte operand types, head_dim 16 or 32");
     constexpr int NDT = HD / 16;
     constexpr int SD = 32 * 2 + 16, ST = 64 * 2 + 16;            // row strides: [token][32 d slots] tiles, v^T [32 d][64 tokens]
@@ -1486,8 +1486,16 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.x;
-    const int w0 = (int)((long long)n_windows * blockIdx.y / gridDim.y), w1 = (int)((long long)n_windows * (blockIdx.y + 1) / gridDim.y);
+    // (head, window chunk) of this workgroup.  Launch order is head-fastest and workgroup i runs on XCD i % 8, so two neighbouring heads -- whose 64-byte pieces of
+    // a dO / dqkv token row share one 128-byte line -- sat on two XCDs and each L2 fetched the whole line: dO came from memory twice (fetch 10.0 GB per step for
+    // 8.1 algorithmic, profiles/r06_pmc_traffic_train.json).  Round 6: units of two heads, unit u on XCD u % 8, its two workgroups in consecutive launch rounds.
+    int h = blockIdx.x, cy = blockIdx.y;
+    if (pair && (heads & 1) == 0 && ((heads * gridDim.y) & 15) == 0) {
+        const unsigned i = blockIdx.x + heads * blockIdx.y, u = (i >> 4) * 8 + (i & 7), hp = (unsigned)heads >> 1;
+        h = (int)(2 * (u % hp) + ((i >> 3) & 1));
+        cy = (int)(u / hp);
+    }
+    const int w0 = (int)((long long)n_windows * cy / gridDim.y), w1 = (int)((long long)n_windows * (cy + 1) / gridDim.y);
     const int i0 = wave * 16;                                      // this wave's query tile (phase A) and key tile (phase B)
     const int nWc = W >> 3, nW = (H >> 3) * nWc;
     const unsigned qb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs, kb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ks;
@@ -1698,7 +1706,7 @@ __global__ __launch_bounds__(256, MK ? 2 : UF_ATTN_BWD2_WPS) void window_attn_bw
         }
         __syncthreads();   // the next window overwrites the tiles
     }
-    float* wb = ws_bias + ((size_t)blockIdx.y * heads + h) * 4096;
+    float* wb = ws_bias + ((size_t)cy * heads + h) * 4096;
 #pragma unroll
     for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(wb + (i0 + fr) * 64 + 16 * t + 4 * fg) = adb[t];
 }
@@ -2060,9 +2068,10 @@ static int window_attention_bwd_any(const void* q, const void* k, const void* vt
         const bool v2 = dtype_half(dtype) && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)dO % 16) == 0;
 #define UF_ATTN_BWD2(TT, HDV)                                                                                                                       \
         if (mask) hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV, true>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
-                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);                            \
+                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift, pair);                      \
         else hipLaunchKernelGGL((window_attn_bwd2_kernel<TT, HDV, false>), dim3(heads, G), dim3(256), 0, st, (const TT*)q, (const TT*)k, (const TT*)vt, bias_dense, mask,      \
-                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift);
+                           n_mask, (const TT*)dO, ldo, (TT*)dq, (TT*)dk, (TT*)dvt, (TT*)dqkv, qscale, (float*)ws, n_windows, heads, H, W, shift, pair);
+        const int pair = variant("attpair", 1);      // UF_VARIANT="attpair=0": (head, chunk) in launch order (A/B runs); same bits either way
         if (v2 && dtype == UF_BF16) { if (head_dim == 32) { UF_ATTN_BWD2(bf16, 32) } else { UF_ATTN_BWD2(bf16, 16) } }
         else if (v2) { if (head_dim == 32) { UF_ATTN_BWD2(f16, 32) } else { UF_ATTN_BWD2(f16, 16) } }
         else
