@@ -1935,7 +1935,7 @@ static int wgrad_chunks(int M, int N, int K, uf_dtype dtype = UF_F32) {
     const int tiles = ((N + T - 1) / T) * ((K + T - 1) / T), steps = (M + 31) / 32;
     // workgroups per launch to aim for: every chunk costs one N x K f32 partial written and read again by the ordered sum, so no more
     // chunks than it takes to fill the chip (128-wide tiles: 2 workgroups per CU resident)
-    const int target = T == 128 ? 512 : 2048;   // 512 vs 1024 vs 2048 measured: 148.8 / 151.0 / 151.1 ms per training step
+    const int target = T == 128 ? 512 : 2048;   // 512 vs 1024 vs 2048 measured: 148.8 / 151.0 / 151.1 ms per training step (round 2); 256 / 384 / 512 / 768: 64.0 / 63.3 / 63.0 / 63.7 (profiles/r06_run20_ab.txt)
     int S = target / tiles;
     if (S > steps) S = steps;
     if (S > 512) S = 512;       // one-tile shapes (C = 32: every weight; C = 64: the projection) had 256 workgroups for 512 slots under the old cap of 256
