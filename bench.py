@@ -20,7 +20,7 @@ fields it carries
     measured on exactly these kernel sources (stamp check), else null;
   * ``cpu_baseline``: the oracle (CPU restatement) on this host: thread count swept, B = 1 and B = 4,
     median of 3 -- plus, for reference, the reference's own model.py as timed in the build container
-    (``reference_container``, from profiles/r02_reference_cpu.json; /root/reference does not exist here);
+    (``reference_container``, from the newest profiles/r*_reference_cpu.json; /root/reference does not exist here);
   * ``--error-budget``: bf16-mode error by source (oracle/bf16_budget.py), one switch at a time.
 """
 from __future__ import annotations
@@ -139,7 +139,8 @@ def cpu_baseline(arch, img, budget_s=28.0):
                       f"{time.perf_counter() - t_start:.0f} s of CPU work on {avail} available logical cores"),
            "b1_images_per_s": v1, "b4_images_per_s": v4, "threads_probed": {str(t): 1.0 / s for t, s in probe.items()}}
     try:                                                   # the reference ITSELF, timed where /root/reference exists
-        with open(os.path.join(REPO, "profiles", "r02_reference_cpu.json")) as f:
+        newest = sorted(f for f in os.listdir(os.path.join(REPO, "profiles")) if f.endswith("_reference_cpu.json"))[-1]      # r06_reference_cpu.json (round 2: r02_...)
+        with open(os.path.join(REPO, "profiles", newest)) as f:
             out["reference_container"] = json.load(f)
     except (OSError, ValueError):
         pass

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the REFERENCE ITSELF (/root/reference/model.py, imported unmodified behind the 3-symbol timm shim of
 tests/golden/make_golden.py) on the CPU cores of the BUILD CONTAINER -- the GPU box has no /root/reference.  Uformer-B 256x256,
-fp32, eval, no_grad, B = 1 and B = 4, median of 3 after a warm-up; written to profiles/r02_reference_cpu.json, which bench.py
+fp32, eval, no_grad, B = 1 and B = 4, median of 3 after a warm-up; written to profiles/r06_reference_cpu.json (round 2: r02_reference_cpu.json), which bench.py
 carries as ``cpu_baseline.reference_container`` next to the oracle timing it measures on the GPU box's own cores.
 
     PYTHONDONTWRITEBYTECODE=1 python scripts/time_reference_cpu.py
@@ -39,7 +39,8 @@ def main():
         out[f"b{B}_images_per_s"] = B / statistics.median(ts)
         out[f"b{B}_seconds_median_of_3"] = statistics.median(ts)
     out["value"] = max(out["b1_images_per_s"], out["b4_images_per_s"])
-    path = os.path.join(REPO, "profiles", "r02_reference_cpu.json")
+    out["round"] = 6
+    path = os.path.join(REPO, "profiles", "r06_reference_cpu.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out))
 
