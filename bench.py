@@ -420,6 +420,61 @@ def p720_tiled_mode(args, dev, ud, dtype_name, steps=3, warmup=1, tile=768, min_
     return out
 
 
+def pipelined_mode(args, model, x, ud, dev, depth=2, small=((4, 4), (1, 4))):
+    """The SAME forwards with up to ``depth`` of them in flight (uformer_amd.infer.PipelinedForward: successive batches on a ring of streams) -- a serving
+    protocol, NOT the line's ``value`` (which stays one forward after the other on one stream, comparable with every earlier round): regions of exactly
+    ``--steps`` forwards of ``--batch`` images between barrier + synchronize pairs, median of ``--repeats`` (at most 5), max over ranks; outputs compared
+    bit for bit with the eager forward.  ``small``: (batch, depth) pairs of the small-batch regime the reference's evaluation scripts run in
+    (test/test_sidd.py:101-107), each against its own eager loop, on rank 0's timing only."""
+    from uformer_amd import infer, spec
+    out = {"depth": depth, "protocol": f"up to {depth} forwards of successive batches in flight, each on its own stream; every handle consumed inside the timed region"}
+    with torch.no_grad():
+        want = model(x).clone()
+        pf = infer.PipelinedForward(model, depth=depth)
+        ys = list(pf.map([x] * (depth + 1)))
+        torch.cuda.synchronize()
+        out["bit_identical_to_eager"] = all(torch.equal(y, want) for y in ys)
+        regions = []
+        for _ in range(max(1, min(args.repeats, 5))):
+            torch.cuda.synchronize(); ud.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _y in pf.map(x for _ in range(args.steps)):
+                pass
+            torch.cuda.synchronize(); ud.barrier()
+            regions.append(ud.max_over_ranks(time.perf_counter() - t0, dev))
+        e = statistics.median(regions)
+        images = ud.sum_over_ranks(float(x.shape[0] * args.steps), dev)
+        out.update({"images_per_s": images / e, "ms_per_step": 1e3 * e / args.steps, "steps": args.steps, "repeats": len(regions),
+                    "images_per_s_min": images / max(regions), "images_per_s_max": images / min(regions)})
+        sb = {}
+        for (b, d) in small:
+            xb = spec.synth_input(b, x.shape[2], x.shape[3], 4321).to(dev)
+            n = max(args.steps, 160 // b)
+            pfb = infer.PipelinedForward(model, depth=d)
+
+            def loop_eager():
+                for _ in range(n):
+                    model(xb)
+
+            def loop_piped():
+                for _y in pfb.map(xb for _ in range(n)):
+                    pass
+            res = {}
+            for name, fn in (("eager", loop_eager), ("pipelined", loop_piped)):
+                fn()
+                ts = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn()
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                res[name] = b * n / statistics.median(ts)
+            sb[f"batch{b}"] = {"depth": d, "eager_images_per_s": res["eager"], "pipelined_images_per_s": res["pipelined"], "forwards_per_region": n}
+        out["small_batch"] = sb
+    return out
+
+
 def build_model(args, cfg, sd, dev, cd):
     from uformer_amd import model as um
     m = um.Uformer(img_size=cfg.img_size, embed_dim=cfg.embed_dim, depths=list(cfg.depths), num_heads=list(cfg.num_heads),
@@ -500,6 +555,7 @@ def main():
     ap.add_argument("--no-other-modes", action="store_true", help="headline mode only (no f16 / bf16 / f32 companions)")
     ap.add_argument("--no-train-mode", action="store_true", help="skip modes.train (BASELINE configs[2])")
     ap.add_argument("--no-720p", action="store_true", help="skip modes.p720 (BASELINE configs[4]: one 1280x720 frame through expand2square -> 1280x1280)")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip modes.pipelined (two forwards of successive batches in flight; small-batch throughput)")
     ap.add_argument("--train-mode-multi", action="store_true", help="(default since round 5; kept for old command lines) run modes.train under N > 1 too")
     ap.add_argument("--train-batch", type=int, default=32)
     ap.add_argument("--train-steps", type=int, default=3)
@@ -559,6 +615,9 @@ def main():
             m2 = build_model(args, cfg, sd, dev, TORCH_DTYPE[other])
             r2 = timed_steps(m2, x, steps2, 2, ud, dev, repeats=1 if other == "f32" else min(args.repeats, 5))
             others[other] = (m2, statistics.median(r2), steps2, ud.sum_over_ranks(float((b - a) * steps2), dev), r2)
+    pipe_entry = None
+    if not args.no_pipelined and not args.no_other_modes:
+        pipe_entry = pipelined_mode(args, model, x, ud, dev)
     train_entry = None
     # modes.train rides along at every N: under N > 1 it is the one place of the path with a collective (the bucketed gradient all-reduce
     # over RCCL, overlapped with the reverse sweep), so a scaling run exercises it by default (--no-train-mode skips it)
@@ -616,6 +675,8 @@ def main():
                                    "mfma_frac_whole_model": v2 * flops_img / 1e12 / world / MFMA_PEAK_TFLOPS[other]}
         if train_entry is not None:
             out["modes"]["train"] = train_entry
+        if pipe_entry is not None:
+            out["modes"]["pipelined"] = pipe_entry
         if p720_entry is not None:
             out["modes"]["p720"] = p720_entry
         if p720t_entry is not None:
@@ -752,6 +813,12 @@ def main():
                            "train_dom_traffic": tr["roofline"].get("traffic")})
             if "cpu_baseline" in tr:
                 sm["train_cpu_img_s"] = round(tr["cpu_baseline"]["value"], 3)
+        if "pipelined" in md:
+            pp = md["pipelined"]
+            sm.update({"pipelined_depth": pp["depth"], "pipelined_img_s": round(pp["images_per_s"], 1), "pipelined_bit_identical": pp["bit_identical_to_eager"]})
+            for k_, v_ in pp.get("small_batch", {}).items():
+                sm[k_ + "_img_s"] = round(v_["eager_images_per_s"], 1)
+                sm[k_ + f"_pipelined{v_['depth']}_img_s"] = round(v_["pipelined_images_per_s"], 1)
         if "p720" in md:
             sm.update({"p720_ms": round(md["p720"]["ms_per_frame"], 2), "p720_fps": round(md["p720"]["frames_per_s"], 1), "p720_mfma_frac": round(md["p720"]["mfma_frac"], 4)})
         if "p720_tiled" in md:

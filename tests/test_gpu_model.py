@@ -352,6 +352,36 @@ def test_graphed_forward_helper_replays_bit_identically():
         assert torch.equal(gf(xs[1]), m(xs[1]))
 
 
+@pytest.mark.parametrize("depth,B", [(1, 2), (2, 8), (3, 8)])
+def test_pipelined_forward_equals_eager(depth, B):
+    """uformer_amd.infer.PipelinedForward (throughput serving: up to ``depth`` forwards of successive batches in flight, each on its own stream; B = 8
+    also takes the library's two half-batch parts inside every forward): outputs in order and equal to the eager forward bit for bit, with fresh
+    inputs, after a parameter change behind drain() (the pack is rebuilt on the caller's stream), and with a consumer kernel on the caller's stream
+    right behind result()."""
+    from uformer_amd import infer
+    cfg = spec.arch_config("tiny32", img_size=128)
+    m = build(cfg, spec.synth_state_dict(cfg, 31), torch.bfloat16)
+    xs = [spec.synth_input(B, 128, 128, 80 + i).cuda() for i in range(7)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+        pf = infer.PipelinedForward(m, depth=depth)
+        got = [y * 1.0 for y in pf.map(xs)]                   # a consumer on the caller's stream behind every result()
+        torch.cuda.synchronize()
+        assert len(got) == len(want)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), (depth, B, i, (g - w).abs().max().item())
+        h0, h1 = pf.submit(xs[0]), pf.submit(xs[1])
+        pf.drain()                                           # parameters may change only behind the forwards in flight
+        m.output_proj.proj[0].bias.add_(0.125)               # new parameters (in place, the version counter moves): the next submit repacks on the caller's stream
+        h2 = pf.submit(xs[1])
+        y0, y1, y2 = h0.result().clone(), h1.result().clone(), h2.result().clone()
+        torch.cuda.synchronize()
+        assert torch.equal(y0, want[0]) and torch.equal(y1, want[1])
+        assert torch.equal(y2, m(xs[1]))
+        y1 = y2
+        assert not torch.equal(y1, want[1])
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_forward_backward_captured_in_a_hip_graph(dtype):
     """Forward + backward of a training step inside ONE HIP graph (torch.cuda.CUDAGraph around the module call and loss.backward()): the

@@ -157,3 +157,73 @@ class GraphedForward:
         self._x.copy_(x)
         self._graph.replay()
         return self._y
+
+
+class PipelinedForward:
+    """Throughput serving, beyond the reference (whose scripts restore one batch after the other, test/test_sidd.py:101-107): up to ``depth``
+    forwards of successive batches IN FLIGHT at once, each on a stream of its own.
+
+    One forward is a chain of ~90 dependent launches, and the deep stages of a 256 x 256 batch do not fill the chip (Uformer-B at batch 16: 64
+    windows in the bottleneck, 256 = one per CU at 32 x 32): with one batch in flight those launches run at the latency of a single window while
+    most of the matrix pipes idle.  Batches are independent, so the next batch's high-resolution stages can run beside them.  ``submit(x)``
+    enqueues a forward on the next stream of a small ring (ordered behind everything the caller's stream has enqueued so far -- the producer of
+    ``x``) and returns a handle; ``handle.result()`` makes the CALLER's stream wait for that forward and returns its output (every handle must be
+    consumed).  Results are the
+    eager forward's bit for bit (the kernels are batch-size and stream invariant, tests/test_gpu_model.py).  The caller keeps ``x`` alive until
+    ``result()``; outputs are fresh tensors.  Parameters must not change while forwards are in flight (the small f32 parameters are read in place,
+    and an update enqueued on the caller's stream is not ordered behind the ring streams): consume every handle, or call ``drain()``, first.
+    Measured on an MI355X, Uformer-B 256 x 256 bf16 (profiles/r06_run21_pipelined.txt): batch 16: 2419 img/s eager, 2566 with two forwards in flight;
+    batch 4: 1190 -> 1836 (2) -> 2177 (3); batch 1: 389 -> 696 (2) -> 945 img/s (3)."""
+
+    class Handle:
+        def __init__(self, y: Tensor, ev, stream):
+            self._y, self._ev, self._stream = y, ev, stream
+
+        def result(self) -> Tensor:
+            cur = torch.cuda.current_stream(self._y.device)
+            cur.wait_event(self._ev)
+            self._y.record_stream(cur)          # allocated on the ring stream, consumed on the caller's
+            return self._y
+
+    def __init__(self, model, depth: int = 2, device=None):
+        if depth < 1:
+            raise ValueError("depth must be at least 1")
+        dev = device if device is not None else next(model.parameters()).device
+        self.model, self.depth = model, depth
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self._k = 0
+
+    @torch.no_grad()
+    def submit(self, x: Tensor) -> "PipelinedForward.Handle":
+        s = self._streams[self._k % self.depth]
+        self._k += 1
+        # the operand pack is (re)built HERE, on the caller's stream, which every ring stream waits for -- not inside the forward on one ring stream while
+        # the others already read it; the handle keeps the pack it ran on alive (a later repack frees the old buffers only after result())
+        get = getattr(self.model, "_get_packed", None)
+        pack = get(x.device) if get is not None else None
+        s.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(s):
+            y = self.model(x)
+            ev = torch.cuda.Event()
+            ev.record(s)
+        x.record_stream(s)
+        h = PipelinedForward.Handle(y, ev, s)
+        h._pack = pack
+        return h
+
+    def drain(self) -> None:
+        """the caller's stream waits for every forward submitted so far (before a parameter update, a checkpoint load, ...)"""
+        cur = torch.cuda.current_stream(self._streams[0].device)
+        for s in self._streams:
+            cur.wait_stream(s)
+
+    @torch.no_grad()
+    def map(self, batches):
+        """Generator: forwards of an iterable of batches, ``depth`` in flight, outputs in order."""
+        pending = []
+        for x in batches:
+            pending.append(self.submit(x))
+            if len(pending) >= self.depth:
+                yield pending.pop(0).result()
+        while pending:
+            yield pending.pop(0).result()

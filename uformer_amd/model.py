@@ -507,7 +507,7 @@ class Uformer(nn.Module):
                                                          # back to the caching allocator's pool of the stream it was allocated (and used) on
         return ws
 
-    MAX_WORKSPACES = 4
+    MAX_WORKSPACES = 8      # (round 6: infer.PipelinedForward drives the module from a ring of streams)
 
     # ---- forward -----------------------------------------------------------------------------
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
