@@ -617,7 +617,14 @@ def main():
             others[other] = (m2, statistics.median(r2), steps2, ud.sum_over_ranks(float((b - a) * steps2), dev), r2)
     pipe_entry = None
     if not args.no_pipelined and not args.no_other_modes:
-        pipe_entry = pipelined_mode(args, model, x, ud, dev)
+        try:
+            pipe_entry = pipelined_mode(args, model, x, ud, dev)
+        except Exception as e:      # noqa: BLE001 -- a companion mode must not take the headline line down (single process); under N > 1 its peers sit in collectives: stop
+            import traceback
+            print(f"[bench rank {rank}] modes.pipelined failed:\n{traceback.format_exc()}", file=sys.stderr, flush=True)
+            pipe_entry = {"error": f"{type(e).__name__}: {e}"[:500]}
+            if world > 1:
+                raise
     train_entry = None
     # modes.train rides along at every N: under N > 1 it is the one place of the path with a collective (the bucketed gradient all-reduce
     # over RCCL, overlapped with the reverse sweep), so a scaling run exercises it by default (--no-train-mode skips it)
@@ -813,7 +820,9 @@ def main():
                            "train_dom_traffic": tr["roofline"].get("traffic")})
             if "cpu_baseline" in tr:
                 sm["train_cpu_img_s"] = round(tr["cpu_baseline"]["value"], 3)
-        if "pipelined" in md:
+        if "pipelined" in md and "error" in md["pipelined"]:
+            sm["pipelined_error"] = md["pipelined"]["error"][:120]
+        elif "pipelined" in md:
             pp = md["pipelined"]
             sm.update({"pipelined_depth": pp["depth"], "pipelined_img_s": round(pp["images_per_s"], 1), "pipelined_bit_identical": pp["bit_identical_to_eager"]})
             for k_, v_ in pp.get("small_batch", {}).items():

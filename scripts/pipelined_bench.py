@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of Uformer-B 256 x 256 (bf16, batch 16 per forward) with 1 / 2 / 3 forwards of successive batches in flight (uformer_amd.infer.PipelinedForward)
+"""Throughput of Uformer-B 256 x 256 (bf16, batch 16 per forward) with 1 / 2 / 3 / 4 forwards of successive batches in flight (uformer_amd.infer.PipelinedForward)
 against the eager loop; bit-identity of the outputs.  UF_STREAMS (read once per process) sets how many parts ONE forward is cut into.
     python scripts/pipelined_bench.py [--batch 16] [--steps 40]"""
 import argparse
@@ -52,7 +52,7 @@ def main():
         dt = region(eager)
         out["eager_ms"] = dt * 1e3
         out["eager_img_s"] = a.batch / dt
-        for depth in (1, 2, 3):
+        for depth in (1, 2, 3, 4):
             pf = infer.PipelinedForward(m, depth=depth)
             ys = list(pf.map(xs))
             torch.cuda.synchronize()
