@@ -507,6 +507,40 @@ def test_samplers_oracle_bigger(dtype):
     check("upsample_256", up.cuda()(xu.cuda(), dtype), O.upsample(xu.to(dtype).float(), pu, ""), dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,H,W,B", [(32, 32, 64, 2), (32, 256, 256, 1), (64, 16, 32, 3), (64, 128, 128, 1), (128, 8, 32, 2), (128, 64, 64, 1), (256, 8, 16, 2), (256, 32, 32, 3)])
+def test_downsample_forms_bit_identical(ops, dtype, C, H, W, B, monkeypatch):
+    """Downsample, second form (uf_gemm.hip down_patch_kernel: the input pixels under a tile of output pixels staged in LDS once, every operand fragment of every
+    tap an LDS read) against the im2col-loader GEMM it replaces at C = 32 ... 256: same K order, same MFMAs -- bit for bit, on maps with image borders
+    inside every tile (the smallest maps are one tile), several images, non-square maps, an input row stride wider than C; and both against the oracle
+    (Conv2d k4 s2 p1, model.py:739-746)."""
+    gen = torch.Generator().manual_seed(11 * C + H + W)
+    ld = C + 8                                                     # rows wider than C: the loader must honour ld_x
+    xw = torch.randn(B * H * W, ld, generator=gen).cuda()
+    x = xw[:, :C]
+    w4 = torch.randn(2 * C, C, 4, 4, generator=gen) / (16 * C) ** 0.5
+    bias = torch.randn(2 * C, generator=gen).cuda()
+    from uformer_amd import packing
+    wp = packing.pack_downsample(w4.cuda(), dtype)
+
+    def run():
+        out = torch.empty(B * (H // 2) * (W // 2), 2 * C, dtype=torch.float32, device="cuda")
+        lib = ops._lib.load()
+        ops._lib.check(lib.uf_downsample_fwd(xw.data_ptr(), ld, wp.data_ptr(), bias.data_ptr(), out.data_ptr(), 2 * C, B, H, W, C, ops.uf_dtype(dtype),
+                                             torch.cuda.current_stream().cuda_stream), "uf_downsample_fwd")
+        return out
+
+    monkeypatch.setenv("UF_VARIANT", "down=1")
+    ref = run()
+    monkeypatch.setenv("UF_VARIANT", "down=2")
+    got = run()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref), f"C={C} {H}x{W} B={B}: the two forms differ, max abs {(got - ref).abs().max().item():.3e}"
+    xi = x.cpu().to(dtype).float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ora = torch.nn.functional.conv2d(xi, w4.to(dtype).float(), bias.cpu(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 2 * C)
+    check(f"downsample_patch_C{C}_{H}x{W}", got, ora, dtype)
+
+
 @pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("N,K", [(48, 16), (96, 32), (768, 256), (512, 2048)])
 def test_fragment_major_packing_bit_exact(ops, dtype, N, K):

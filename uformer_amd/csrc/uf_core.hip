@@ -22,6 +22,8 @@ static thread_local char g_err[512] = "";
 //   gemm_dma=0|1    gemm_kernel: register-staged / LDS-DMA operand staging on every shape that supports it
 //   wgrad4=0|1      linear_wgrad4 (256 x 256 tiles) never / on every shape it supports
 //   stem=1, head=1  the first (global-load) forms of input_proj / output_proj instead of the LDS-staged ones
+//   down=1|2        Downsample: the im2col-loader GEMM everywhere / the LDS-patch form wherever it is built (round 6)
+//   attpair=0       window_attn_bwd2: (head, chunk) in launch order instead of head pairs per XCD (round 6)
 // Read per call (a getenv and a scan of a short string beside a kernel launch): the tests flip keys inside one process.  Returns `dflt` without the key.
 int variant(const char* key, int dflt) {
     const char* e = getenv("UF_VARIANT");

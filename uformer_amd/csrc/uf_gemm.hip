@@ -517,6 +517,174 @@ int launch_bn(const GemmParams& p, hipStream_t stream) {
     return launch_cfg<T, 128, 2, 2, AL, EP>(p, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Downsample, second form (round 6; 2-byte operand types, C = 32 / 64 / 128 / 256, output maps that are whole tiles).
+// The im2col loader above gathers every K tile of the activation operand from HBM / L2 again for every N tile (address arithmetic, two f32 loads, a
+// conversion and a 16-byte LDS store per chunk), and an input pixel belongs to four patches: at 16 x 16 (M = 4096, N = 512, K = 4096) the launch ran at
+// 230 TFLOP/s, bound by the loader's own instruction stream (three K tiles in flight instead of one changed nothing: profiles/r06_run26_down.txt).
+// Here a workgroup owns TOY x TOX OUTPUT pixels, stages the (2 TOY + 2) x (2 TOX + 2) input pixels under them ONCE -- converted to the operand type,
+// zero outside the image -- and every MFMA operand fragment of every tap is a 16-byte LDS read at (2 oy + ky, 2 ox + kx).  The four waves split the BN
+// output channels; weight fragments stream L2 -> registers through a ring of RING k-steps (row-major T[N][K], no LDS, no barrier in the K loop).
+// Pixel pitch = 2 C + 16 bytes: two neighbouring output pixels are 2 pitches = 32 (C = 32: 160) bytes mod 256 apart, so the 16 lanes of a fragment read
+// hit 16 different 16-byte bank groups; with 8-pixel output rows (C = 256) the row pitch is padded to a multiple of 128 bytes for the same reason.
+// Same K order (tap-major, 32-channel steps), same MFMAs, accumulators from zero, bias added at the end: bit-identical to the first form
+// (tests/test_gpu_ops.py::test_downsample_forms_bit_identical; UF_VARIANT="down=1" selects the first form).
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T, int C, int TOY, int TOX, int BN, int RING>
+__global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const GemmParams p, int tiles_x, int tiles_y) {
+    static_assert(sizeof(T) == 2 && (TOX == 16 || TOX == 8) && BN % 64 == 0, "2-byte operand types; 16- or 8-pixel tile rows; four waves split BN");
+    constexpr int PH = 2 * TOY + 2, PW = 2 * TOX + 2;
+    constexpr int PP = C * 2 + 16;                                              // pixel pitch in LDS (bytes)
+    constexpr int RP = TOX == 8 ? (PW * PP + 127) / 128 * 128 : PW * PP;        // row pitch
+    constexpr int TM = TOY * TOX / 16, TN = BN / 64;                            // 16-token tiles of the workgroup, 16-channel tiles of a wave
+    constexpr int K = 16 * C, KSN = K / 32, CS = C / 32;                         // k-steps in all, k-steps per tap
+    static_assert(KSN % RING == 0, "ring divides the k-steps");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n_tiles = p.N / BN;
+    const int lid = xcd_tile((int)blockIdx.x, (int)gridDim.x);                  // every XCD walks one contiguous run of (tile, N tile) pairs: halo pixels and N tiles share an L2
+    const int tile = lid / n_tiles, n0 = (lid - tile * n_tiles) * BN + wave * (16 * TN);
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+    const int oy0 = (tr / tiles_x) * TOY, ox0 = (tr % tiles_x) * TOX;
+    const int H = p.H, W = p.W_;
+    const T* Wt = reinterpret_cast<const T*>(p.W);
+
+    // weight ring: the first RING - 1 k-steps are requested before the patch is staged
+    const T* wrow[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wrow[i] = Wt + (size_t)(n0 + 16 * i + fr) * K + fg * 8;
+    Frag<T> wf[RING][TN];
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)
+#pragma unroll
+        for (int i = 0; i < TN; ++i) load_frag(wf[r][i], wrow[i] + r * 32);
+
+    // ---- stage the input patch: chunk = 8 channels of one pixel (32 bytes of f32 in, 16 bytes of T out), eight chunks per thread in flight
+    {
+        constexpr int CPP = C / 8, NCH = PH * PW * CPP, U = 8;
+        const float* xb = reinterpret_cast<const float*>(p.A);
+        const int iy0 = 2 * oy0 - 1, ix0 = 2 * ox0 - 1;
+#pragma unroll 1
+        for (int q0 = tid; q0 < NCH; q0 += 256 * U) {
+            u32x4 lo[U], hi[U];
+            bool ok[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 256 * u, qc = q < NCH ? q : NCH - 1;
+                const int pix = qc / CPP, cc = qc - pix * CPP, pr = pix / PW, pc = pix - pr * PW;
+                const int iy = iy0 + pr, ix = ix0 + pc;
+                ok[u] = q < NCH && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const int iyc = iy < 0 ? 0 : (iy >= H ? H - 1 : iy), ixc = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+                const float* src = xb + ((size_t)(b * H + iyc) * W + ixc) * p.lda + cc * 8;
+                lo[u] = *reinterpret_cast<const u32x4*>(src);
+                hi[u] = *(reinterpret_cast<const u32x4*>(src) + 1);
+                dst[u] = q < NCH ? pr * RP + pc * PP + cc * 16 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                u32x4 v = u32x4{pack2<T>(__uint_as_float(lo[u][0]), __uint_as_float(lo[u][1])), pack2<T>(__uint_as_float(lo[u][2]), __uint_as_float(lo[u][3])),
+                                pack2<T>(__uint_as_float(hi[u][0]), __uint_as_float(hi[u][1])), pack2<T>(__uint_as_float(hi[u][2]), __uint_as_float(hi[u][3]))};
+                if (!ok[u]) v = u32x4{0, 0, 0, 0};
+                if (dst[u] >= 0) *reinterpret_cast<u32x4*>(smem + dst[u]) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // per-lane patch offsets of the lane's token in each 16-token tile (tap (0, 0), channel group fg)
+    int abase[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int oyl = TOX == 16 ? j : 2 * j + (fr >> 3), oxl = TOX == 16 ? fr : (fr & 7);
+        abase[j] = 2 * oyl * RP + 2 * oxl * PP + fg * 16;
+    }
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fully unrolled: across a loop back-edge the compiler's wait-count insertion falls back to "everything but the last k-step's loads has landed" at the top
+    // of every turn (s_waitcnt vmcnt(TN) in the ISA), which drains the ring once per RING k-steps
+#pragma unroll
+    for (int ks0 = 0; ks0 < KSN; ks0 += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            const int ks = ks0 + r;
+            if (ks + RING - 1 < KSN) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) load_frag(wf[(r + RING - 1) % RING][i], wrow[i] + (ks + RING - 1) * 32);
+            }
+            const int tap = ks / CS, koff = (tap >> 2) * RP + (tap & 3) * PP + (ks - tap * CS) * 64;     // wave-uniform
+            Frag<T> af[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) load_frag(af[j], reinterpret_cast<const T*>(smem + abase[j] + koff));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[r][i], af[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    const int Ho = H >> 1, Wo = W >> 1;
+    float* out = reinterpret_cast<float*>(p.out);
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int n = n0 + 16 * i + 4 * fg;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int oyl = TOX == 16 ? j : 2 * j + (fr >> 3), oxl = TOX == 16 ? fr : (fr & 7);
+            const size_t m = (size_t)(b * Ho + oy0 + oyl) * Wo + ox0 + oxl;
+            *reinterpret_cast<f32x4*>(out + m * p.ldo + n) = acc[i][j] + bv;
+        }
+    }
+}
+
+template <typename T, int C, int TOY, int TOX, int BN, int RING>
+int launch_down_patch(const GemmParams& p, hipStream_t stream) {
+    constexpr int PW = 2 * TOX + 2, PP = C * 2 + 16, RP = TOX == 8 ? (PW * PP + 127) / 128 * 128 : PW * PP;
+    constexpr int smem = (2 * TOY + 2) * RP;
+    auto kern = down_patch_kernel<T, C, TOY, TOX, BN, RING>;
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "downsample")) return rc;
+    const int Ho = p.H / 2, Wo = p.W_ / 2, tiles_x = Wo / TOX, tiles_y = Ho / TOY, B = p.M / (Ho * Wo);
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "down_patch_%s_c%d %dx%dx%d", TypeName<T>::s, C, p.M, p.N, p.K);
+    {
+        ScopedTimer tm(name, 2.0 * p.M * (double)p.N * p.K, (double)p.M * p.K + (double)p.N * p.K * sizeof(T) + (double)p.M * p.N * 4, stream);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles_x * tiles_y * (p.N / BN))), dim3(256), smem, stream, p, tiles_x, tiles_y);
+    }
+    return check_launch("downsample");
+}
+
+// the second form where it is built: 2-byte operands, C = 32 ... 256, N = 2 C, K = 16 C, whole tiles, rows of 4 f32 channels aligned
+template <typename T>
+int try_down_patch(const GemmParams& p, hipStream_t stream, bool* done) {
+    *done = false;
+    if constexpr (sizeof(T) == 2) {
+        const int dv = variant("down", 0);                  // UF_VARIANT="down=1": the first form everywhere; "down=2": the second wherever it is built (tests, A/B runs)
+        if (dv == 1) return UF_OK;
+        const int C = p.C, Ho = p.H / 2, Wo = p.W_ / 2;
+        if (p.N != 2 * C || p.K != 16 * C || p.lda % 4 || p.ldo % 4 || Ho <= 0 || Wo <= 0 || p.M % (Ho * Wo) || (p.H & 1) || (p.W_ & 1)) return UF_OK;
+        if ((long long)p.M * p.ldo >= 0x7fffffffLL * 4) return UF_OK;
+        *done = true;
+        if (C == 32 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 32, 8, 16, 64, 8>(p, stream);
+        if (C == 64 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 64, 8, 16, 128, 8>(p, stream);
+        // C >= 128: one workgroup per CU (the patch is 90 KB) streaming 1-2 MB of weights -- a win while the launch is ONE round of workgroups, slower than the
+        // first form beyond it (batch 32: 83 vs 71 us at C = 128, 132 vs 103 at C = 256; batch 16: 42 vs 53, 67 vs 76; profiles/r06_run28_down.txt)
+        if (C == 128 && Ho % 4 == 0 && Wo % 16 == 0 && (dv == 2 || p.M / 64 <= 256)) return launch_down_patch<T, 128, 4, 16, 256, 4>(p, stream);
+        if (C == 256 && Ho % 4 == 0 && Wo % 8 == 0 && (dv == 2 || p.M / 32 * 2 <= 256)) return launch_down_patch<T, 256, 4, 8, 256, 8>(p, stream);
+        *done = false;
+    }
+    return UF_OK;
+}
+
 template <typename T>
 int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
     if (aload == A_PLAIN) {
@@ -531,6 +699,9 @@ int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
             default: break;
         }
     } else if (aload == A_CONV_DOWN && epi == E_STORE_R) {
+        bool done = false;
+        const int rc = try_down_patch<T>(p, stream, &done);
+        if (rc || done) return rc;
         return launch_bn<T, A_CONV_DOWN, E_STORE_R>(p, stream);
     } else if (aload == A_FROM_R && epi == E_UPSAMPLE) {
         return launch_bn<T, A_FROM_R, E_UPSAMPLE>(p, stream);
