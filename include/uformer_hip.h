@@ -217,6 +217,11 @@ int uf_lewin_block_train_fwd(const uf_block_params* p, float* x, int ld, int B, 
  * [B][H/2][W/2] rows of 2C (stride ld_o). */
 int uf_downsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out,
                       int ld_o, int B, int H, int W, int C, uf_dtype dtype, void* stream);
+/* The same with the weight ALSO in the fragment-major layout of uf_pack_weight_fm(w, w_fm, 2C, 16C) (round 6): where the second form of the kernel is built
+ * (2-byte operand types, C = 32 / 64 / 128 / 256, output maps that are whole tiles) it streams w_fm -- contiguous KiB per wave-instruction instead of 16 rows x 64
+ * bytes -- and is bit-identical to uf_downsample_fwd; everywhere else, and with w_fm = NULL, it IS uf_downsample_fwd. */
+int uf_downsample_fm_fwd(const float* x, int ld_x, const void* w, const void* w_fm, const float* bias, float* out,
+                         int ld_o, int B, int H, int W, int C, uf_dtype dtype, void* stream);
 /* ---- a13: Upsample.forward (ConvTranspose2d k2 s2, model.py:765-771) written straight into
  * the concat buffer: out rows (stride ld_o) at [B][2H][2W], channels [0,Cout).
  * w T[4*Cout][Cin], n = (dy*2+dx)*Cout + co. */
@@ -506,6 +511,7 @@ typedef struct uf_model_desc {
     const float* down_b[4];
     const void* up_w[4];   /* upsample_i.deconv.0.weight repacked T[4Cout][Cin] */
     const float* up_b[4];
+    const void* down_w_fm[4]; /* (round 6, appended) down_w in the fragment-major layout of uf_pack_weight_fm(down_w, ., 2C, 16C), or NULL: see uf_downsample_fm_fwd */
 } uf_model_desc;
 
 size_t uf_uformer_workspace_bytes(const uf_model_desc* d, int B, int H, int W, uf_dtype dtype);

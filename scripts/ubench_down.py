@@ -37,10 +37,11 @@ def main():
         x = torch.randn(B * H * H, C, device="cuda", generator=g)
         w = (torch.randn(2 * C, 16 * C, device="cuda", generator=g) / (16 * C) ** 0.5).to(T)
         b = torch.randn(2 * C, device="cuda", generator=g)
-        y = ops.downsample(x, w, b, B, H, H)
+        wf = ops.pack_weight_fm(w) if (T != torch.float32 and os.environ.get("DOWN_NO_FM") is None) else None      # DOWN_NO_FM=1: the row-major weight only
+        y = ops.downsample(x, w, b, B, H, H, w_fm=wf)
         torch.cuda.synchronize()
         h.update(y.cpu().numpy().tobytes())
-        us = timeit(lambda: ops.downsample(x, w, b, B, H, H))
+        us = timeit(lambda: ops.downsample(x, w, b, B, H, H, w_fm=wf))
         M, N, K = B * H * H // 4, 2 * C, 16 * C
         by = x.numel() * 4 + y.numel() * 4 + w.numel() * w.element_size()
         tot += us

@@ -530,12 +530,23 @@ def test_downsample_forms_bit_identical(ops, dtype, C, H, W, B, monkeypatch):
                                              torch.cuda.current_stream().cuda_stream), "uf_downsample_fwd")
         return out
 
+    def run_fm():
+        out = torch.empty(B * (H // 2) * (W // 2), 2 * C, dtype=torch.float32, device="cuda")
+        lib = ops._lib.load()
+        wfm = ops.pack_weight_fm(wp)
+        ops._lib.check(lib.uf_downsample_fm_fwd(xw.data_ptr(), ld, wp.data_ptr(), wfm.data_ptr(), bias.data_ptr(), out.data_ptr(), 2 * C, B, H, W, C, ops.uf_dtype(dtype),
+                                                torch.cuda.current_stream().cuda_stream), "uf_downsample_fm_fwd")
+        return out
+
     monkeypatch.setenv("UF_VARIANT", "down=1")
     ref = run()
     monkeypatch.setenv("UF_VARIANT", "down=2")
     got = run()
+    monkeypatch.delenv("UF_VARIANT")
+    got_fm = run_fm()                                             # the same form streaming the fragment-major pack of the weight (uf_downsample_fm_fwd)
     torch.cuda.synchronize()
     assert torch.equal(got, ref), f"C={C} {H}x{W} B={B}: the two forms differ, max abs {(got - ref).abs().max().item():.3e}"
+    assert torch.equal(got_fm, ref), f"C={C} {H}x{W} B={B}: the fragment-major weight stream differs, max abs {(got_fm - ref).abs().max().item():.3e}"
     xi = x.cpu().to(dtype).float().reshape(B, H, W, C).permute(0, 3, 1, 2)
     ora = torch.nn.functional.conv2d(xi, w4.to(dtype).float(), bias.cpu(), stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 2 * C)
     check(f"downsample_patch_C{C}_{H}x{W}", got, ora, dtype)

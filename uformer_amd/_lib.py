@@ -55,6 +55,7 @@ class ModelDesc(C.Structure):
         ("in_w27", C.c_void_p), ("in_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
         ("down_w", C.c_void_p * 4), ("down_b", C.c_void_p * 4),
         ("up_w", C.c_void_p * 4), ("up_b", C.c_void_p * 4),
+        ("down_w_fm", C.c_void_p * 4),
     ]
 
 
@@ -109,6 +110,7 @@ SIGNATURES = {
     "uf_lewin_block_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, I, I, P, c_size_t, P]),
     "uf_lewin_block_train_fwd": (I, [C.POINTER(BlockParams), P, I, I, I, I, I, P, P, I, P, c_size_t, P]),
     "uf_downsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, P]),
+    "uf_downsample_fm_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, I, P]),
     "uf_upsample_fwd": (I, [P, I, P, P, P, I, I, I, I, I, I, I, P]),
     "uf_input_proj_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "uf_output_proj_fwd": (I, [P, I, P, P, P, P, I, I, I, I, I, P]),

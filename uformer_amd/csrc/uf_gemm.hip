@@ -524,13 +524,16 @@ int launch_bn(const GemmParams& p, hipStream_t stream) {
 // 230 TFLOP/s, bound by the loader's own instruction stream (three K tiles in flight instead of one changed nothing: profiles/r06_run26_down.txt).
 // Here a workgroup owns TOY x TOX OUTPUT pixels, stages the (2 TOY + 2) x (2 TOX + 2) input pixels under them ONCE -- converted to the operand type,
 // zero outside the image -- and every MFMA operand fragment of every tap is a 16-byte LDS read at (2 oy + ky, 2 ox + kx).  The four waves split the BN
-// output channels; weight fragments stream L2 -> registers through a ring of RING k-steps (row-major T[N][K], no LDS, no barrier in the K loop).
+// output channels; weight fragments stream L2 -> registers through a ring of RING k-steps (no LDS, no barrier in the K loop) -- from the FRAGMENT-MAJOR pack
+// (uf_pack_weight_fm: one contiguous KiB per wave-instruction; FM = true, uf_downsample_fm_fwd) or from the row-major T[N][K] (16 rows x 64 bytes per
+// wave-instruction: every 128-byte line is asked for twice, a k-step apart, and at C >= 128 it has left the L1 in between -- 42 / 67 us against
+// 24.5 / 28 us at C = 128 / 256, profiles/r06_run29_fm.txt).
 // Pixel pitch = 2 C + 16 bytes: two neighbouring output pixels are 2 pitches = 32 (C = 32: 160) bytes mod 256 apart, so the 16 lanes of a fragment read
 // hit 16 different 16-byte bank groups; with 8-pixel output rows (C = 256) the row pitch is padded to a multiple of 128 bytes for the same reason.
 // Same K order (tap-major, 32-channel steps), same MFMAs, accumulators from zero, bias added at the end: bit-identical to the first form
 // (tests/test_gpu_ops.py::test_downsample_forms_bit_identical; UF_VARIANT="down=1" selects the first form).
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int C, int TOY, int TOX, int BN, int RING>
+template <typename T, int C, int TOY, int TOX, int BN, int RING, bool FM>
 __global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const GemmParams p, int tiles_x, int tiles_y) {
     static_assert(sizeof(T) == 2 && (TOX == 16 || TOX == 8) && BN % 64 == 0, "2-byte operand types; 16- or 8-pixel tile rows; four waves split BN");
     constexpr int PH = 2 * TOY + 2, PW = 2 * TOX + 2;
@@ -550,16 +553,18 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const 
     const int oy0 = (tr / tiles_x) * TOY, ox0 = (tr % tiles_x) * TOX;
     const int H = p.H, W = p.W_;
     const T* Wt = reinterpret_cast<const T*>(p.W);
+    const T* Wf = reinterpret_cast<const T*>(p.W_fm);
+    constexpr int KSTR = FM ? 512 : 32;                                          // elements between the k-steps of a lane's fragment stream
 
     // weight ring: the first RING - 1 k-steps are requested before the patch is staged
     const T* wrow[TN];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) wrow[i] = Wt + (size_t)(n0 + 16 * i + fr) * K + fg * 8;
+    for (int i = 0; i < TN; ++i) wrow[i] = FM ? Wf + ((size_t)(n0 / 16 + i) * KSN * 64 + lane) * 8 : Wt + (size_t)(n0 + 16 * i + fr) * K + fg * 8;
     Frag<T> wf[RING][TN];
 #pragma unroll
     for (int r = 0; r < RING - 1; ++r)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) load_frag(wf[r][i], wrow[i] + r * 32);
+        for (int i = 0; i < TN; ++i) load_frag(wf[r][i], wrow[i] + r * KSTR);
 
     // ---- stage the input patch: chunk = 8 channels of one pixel (32 bytes of f32 in, 16 bytes of T out), eight chunks per thread in flight
     {
@@ -616,7 +621,7 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const 
             const int ks = ks0 + r;
             if (ks + RING - 1 < KSN) {
 #pragma unroll
-                for (int i = 0; i < TN; ++i) load_frag(wf[(r + RING - 1) % RING][i], wrow[i] + (ks + RING - 1) * 32);
+                for (int i = 0; i < TN; ++i) load_frag(wf[(r + RING - 1) % RING][i], wrow[i] + (ks + RING - 1) * KSTR);
             }
             const int tap = ks / CS, koff = (tap >> 2) * RP + (tap & 3) * PP + (ks - tap * CS) * 64;     // wave-uniform
             Frag<T> af[TM];
@@ -646,21 +651,26 @@ __global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const 
     }
 }
 
-template <typename T, int C, int TOY, int TOX, int BN, int RING>
-int launch_down_patch(const GemmParams& p, hipStream_t stream) {
+template <typename T, int C, int TOY, int TOX, int BN, int RING, bool FM>
+int launch_down_patch_fm(const GemmParams& p, hipStream_t stream) {
     constexpr int PW = 2 * TOX + 2, PP = C * 2 + 16, RP = TOX == 8 ? (PW * PP + 127) / 128 * 128 : PW * PP;
     constexpr int smem = (2 * TOY + 2) * RP;
-    auto kern = down_patch_kernel<T, C, TOY, TOX, BN, RING>;
+    auto kern = down_patch_kernel<T, C, TOY, TOX, BN, RING, FM>;
     static bool lds_done[64] = {};
     if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "downsample")) return rc;
     const int Ho = p.H / 2, Wo = p.W_ / 2, tiles_x = Wo / TOX, tiles_y = Ho / TOY, B = p.M / (Ho * Wo);
     char name[96] = "";
-    if (timing_enabled()) snprintf(name, sizeof(name), "down_patch_%s_c%d %dx%dx%d", TypeName<T>::s, C, p.M, p.N, p.K);
+    if (timing_enabled()) snprintf(name, sizeof(name), "down_patch_%s_c%d%s %dx%dx%d", TypeName<T>::s, C, FM ? "_fm" : "", p.M, p.N, p.K);
     {
         ScopedTimer tm(name, 2.0 * p.M * (double)p.N * p.K, (double)p.M * p.K + (double)p.N * p.K * sizeof(T) + (double)p.M * p.N * 4, stream);
         hipLaunchKernelGGL(kern, dim3((unsigned)(B * tiles_x * tiles_y * (p.N / BN))), dim3(256), smem, stream, p, tiles_x, tiles_y);
     }
     return check_launch("downsample");
+}
+
+template <typename T, int C, int TOY, int TOX, int BN, int RING>
+int launch_down_patch(const GemmParams& p, hipStream_t stream) {
+    return p.W_fm ? launch_down_patch_fm<T, C, TOY, TOX, BN, RING, true>(p, stream) : launch_down_patch_fm<T, C, TOY, TOX, BN, RING, false>(p, stream);
 }
 
 // the second form where it is built: 2-byte operands, C = 32 ... 256, N = 2 C, K = 16 C, whole tiles, rows of 4 f32 channels aligned
@@ -676,10 +686,10 @@ int try_down_patch(const GemmParams& p, hipStream_t stream, bool* done) {
         *done = true;
         if (C == 32 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 32, 8, 16, 64, 8>(p, stream);
         if (C == 64 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 64, 8, 16, 128, 8>(p, stream);
-        // C >= 128: one workgroup per CU (the patch is 90 KB) streaming 1-2 MB of weights -- a win while the launch is ONE round of workgroups, slower than the
+        // C >= 128 with ROW-MAJOR weights: one workgroup per CU (the patch is 90 KB) streaming 1-2 MB of weights -- a win while the launch is ONE round of workgroups, slower than the
         // first form beyond it (batch 32: 83 vs 71 us at C = 128, 132 vs 103 at C = 256; batch 16: 42 vs 53, 67 vs 76; profiles/r06_run28_down.txt)
-        if (C == 128 && Ho % 4 == 0 && Wo % 16 == 0 && (dv == 2 || p.M / 64 <= 256)) return launch_down_patch<T, 128, 4, 16, 256, 4>(p, stream);
-        if (C == 256 && Ho % 4 == 0 && Wo % 8 == 0 && (dv == 2 || p.M / 32 * 2 <= 256)) return launch_down_patch<T, 256, 4, 8, 256, 8>(p, stream);
+        if (C == 128 && Ho % 4 == 0 && Wo % 16 == 0 && (dv == 2 || p.W_fm || p.M / 64 <= 256)) return launch_down_patch<T, 128, 4, 16, 256, 4>(p, stream);
+        if (C == 256 && Ho % 4 == 0 && Wo % 8 == 0 && (dv == 2 || p.W_fm || p.M / 32 * 2 <= 256)) return launch_down_patch<T, 256, 4, 8, 256, 8>(p, stream);
         *done = false;
     }
     return UF_OK;

@@ -20,6 +20,7 @@ enum Epi {
 struct GemmParams {
     const void* A; int lda;     // A_PLAIN: T[M][lda]; A_FROM_R / A_CONV_DOWN: f32 rows of stride lda
     const void* W;              // T[N][K]
+    const void* W_fm = nullptr; // Downsample second form: the same weight in the fragment-major layout of uf_pack_weight_fm (optional)
     const float* bias;
     int M, N, K;
     int H, W_, C;               // geometry: conv-down input (H,W,C); winrev (H,W); upsample input (H,W)

@@ -184,6 +184,18 @@ extern "C" int uf_downsample_fwd(const float* x, int ld_x, const void* w, const 
     return launch_gemm(g, A_CONV_DOWN, E_STORE_R, dtype, (hipStream_t)stream);
 }
 
+extern "C" int uf_downsample_fm_fwd(const float* x, int ld_x, const void* w, const void* w_fm, const float* bias, float* out, int ld_o, int B,
+                                    int H, int W, int C, uf_dtype dtype, void* stream) {
+    UF_REQUIRE(x && w && bias && out, UF_ERR_NULL, "uf_downsample_fm_fwd: null pointer");
+    UF_REQUIRE(B > 0 && H % 2 == 0 && W % 2 == 0 && H > 0 && W > 0, UF_ERR_SHAPE, "uf_downsample_fm_fwd: H=%d W=%d", H, W);
+    UF_REQUIRE(ld_x >= C && ld_o >= 2 * C && ld_o % 4 == 0, UF_ERR_SHAPE, "uf_downsample_fm_fwd: ld_x=%d ld_o=%d C=%d", ld_x, ld_o, C);
+    UF_REQUIRE(!w_fm || ((uintptr_t)w_fm % 16) == 0, UF_ERR_ALIGN, "uf_downsample_fm_fwd: w_fm must be 16-byte aligned");
+    GemmParams g{};
+    g.A = x; g.lda = ld_x; g.W = w; g.W_fm = dtype_half(dtype) ? w_fm : nullptr; g.bias = bias; g.M = B * (H / 2) * (W / 2); g.N = 2 * C; g.K = 16 * C;
+    g.H = H; g.W_ = W; g.C = C; g.out = out; g.ldo = ld_o;
+    return launch_gemm(g, A_CONV_DOWN, E_STORE_R, dtype, (hipStream_t)stream);
+}
+
 extern "C" int uf_upsample_fwd(const float* x, int ld_x, const void* w, const float* bias, float* out, int ld_o, int B, int H,
                                int W, int Cin, int Cout, uf_dtype dtype, void* stream) {
     UF_REQUIRE(x && w && bias && out, UF_ERR_NULL, "uf_upsample_fwd: null pointer");
@@ -293,7 +305,7 @@ int forward_one_stream(const uf_model_desc* d, const float* img, float* out, int
         if (rc) return rc;
         float* nx; int nld;
         if (s < 3) enc_view(s + 1, nx, nld); else { nx = P; nld = pl.C[4]; }
-        rc = uf_downsample_fwd(x, ld, d->down_w[s], d->down_b[s], nx, nld, B, pl.res[s], pl.res[s], pl.C[s], dtype, st);
+        rc = uf_downsample_fm_fwd(x, ld, d->down_w[s], d->down_w_fm[s], d->down_b[s], nx, nld, B, pl.res[s], pl.res[s], pl.C[s], dtype, st);
         if (rc) return rc;
         x = nx; ld = nld;
     }

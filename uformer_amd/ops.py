@@ -524,15 +524,25 @@ def lewin_attn_train_fwd(bp, x: Tensor, B: int, H: int, W: int, heads: int, dtyp
     return x1, xn, q, k, vt, o, z, a1
 
 
-def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int) -> Tensor:
-    """x f32 (B*H*W, C) -> f32 (B*H/2*W/2, 2C).  Downsample.forward model.py:739-746."""
+def pack_weight_fm(w: Tensor) -> Tensor:
+    """Row-major (N, K) weight of a 2- or 4-byte operand type -> the fragment-major layout of ``uf_pack_weight_fm`` (N a multiple of 16)."""
+    return _pack_frag(w)
+
+
+def downsample(x: Tensor, w_packed: Tensor, bias: Tensor, B: int, H: int, W: int, w_fm: Optional[Tensor] = None) -> Tensor:
+    """x f32 (B*H*W, C) -> f32 (B*H/2*W/2, 2C).  Downsample.forward model.py:739-746.  ``w_fm``: ``pack_weight_fm(w_packed)`` if the caller has it
+    (the LDS-patch form of the kernel then streams it; same bits either way)."""
     _dev(x, w_packed, bias)
     x = _c(x, torch.float32)
     Cc = x.shape[-1]
     out = torch.empty((B * (H // 2) * (W // 2), 2 * Cc), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().uf_downsample_fwd(_ptr(x), Cc, _ptr(_c(w_packed)), _ptr(_c(bias, torch.float32)), _ptr(out),
-                                                 2 * Cc, B, H, W, Cc, uf_dtype(w_packed.dtype), _stream()), "uf_downsample_fwd")
+        if w_fm is not None:
+            _lib.check(_lib.load().uf_downsample_fm_fwd(_ptr(x), Cc, _ptr(_c(w_packed)), _ptr(_c(w_fm)), _ptr(_c(bias, torch.float32)), _ptr(out),
+                                                        2 * Cc, B, H, W, Cc, uf_dtype(w_packed.dtype), _stream()), "uf_downsample_fm_fwd")
+        else:
+            _lib.check(_lib.load().uf_downsample_fwd(_ptr(x), Cc, _ptr(_c(w_packed)), _ptr(_c(bias, torch.float32)), _ptr(out),
+                                                     2 * Cc, B, H, W, Cc, uf_dtype(w_packed.dtype), _stream()), "uf_downsample_fwd")
     return out
 
 

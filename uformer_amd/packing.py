@@ -145,5 +145,11 @@ class PackedModel:
             uw = pack_upsample(sd[f"upsample_{k}.deconv.0.weight"], dtype)
             ub = sd[f"upsample_{k}.deconv.0.bias"].detach().float().clone().contiguous()
             d.down_w[k], d.down_b[k], d.up_w[k], d.up_b[k] = dw.data_ptr(), db.data_ptr(), uw.data_ptr(), ub.data_ptr()
-            self.keep.append((dw, db, uw, ub))
+            # round 6: the Downsample weight also in the fragment-major layout its second form streams (2-byte operand types; N = 2C a multiple of 16)
+            dwf = None
+            if dtype in (torch.bfloat16, torch.float16) and dw.is_cuda and dw.shape[0] % 16 == 0 and dw.shape[1] % 32 == 0:
+                from . import ops
+                dwf = ops.pack_weight_fm(dw)
+            d.down_w_fm[k] = dwf.data_ptr() if dwf is not None else None
+            self.keep.append((dw, db, uw, ub, dwf))
         self.desc = d

@@ -490,7 +490,9 @@ class UformerTape:
             t = stage_fwd(s, t)
             self.skips.append(t)
             self.down_in.append(t)
-            t = ops.downsample(t, packing.pack_downsample(sd[f"dowsample_{s}.conv.0.weight"], T), sd[f"dowsample_{s}.conv.0.bias"], B, res[s], res[s])
+            wd = packing.pack_downsample(sd[f"dowsample_{s}.conv.0.weight"], T)
+            wd_fm = ops.pack_weight_fm(wd) if (T in (torch.bfloat16, torch.float16) and wd.shape[0] % 16 == 0 and wd.shape[1] % 32 == 0) else None     # the LDS-patch form streams it (round 6)
+            t = ops.downsample(t, wd, sd[f"dowsample_{s}.conv.0.bias"], B, res[s], res[s], w_fm=wd_fm)
         t = stage_fwd(4, t)
         for k in range(4):
             self.up_in.append(t)
