@@ -534,7 +534,7 @@ int launch_bn(const GemmParams& p, hipStream_t stream) {
 // (tests/test_gpu_ops.py::test_downsample_forms_bit_identical; UF_VARIANT="down=1" selects the first form).
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T, int C, int TOY, int TOX, int BN, int RING, bool FM>
-__global__ __launch_bounds__(256, C == 32 ? 3 : 1) void down_patch_kernel(const GemmParams p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, C == 32 ? 3 : (C == 64 && TOY == 4 ? 3 : 1)) void down_patch_kernel(const GemmParams p, int tiles_x, int tiles_y) {
     static_assert(sizeof(T) == 2 && (TOX == 16 || TOX == 8) && BN % 64 == 0, "2-byte operand types; 16- or 8-pixel tile rows; four waves split BN");
     constexpr int PH = 2 * TOY + 2, PW = 2 * TOX + 2;
     constexpr int PP = C * 2 + 16;                                              // pixel pitch in LDS (bytes)
@@ -685,6 +685,9 @@ int try_down_patch(const GemmParams& p, hipStream_t stream, bool* done) {
         if ((long long)p.M * p.ldo >= 0x7fffffffLL * 4) return UF_OK;
         *done = true;
         if (C == 32 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 32, 8, 16, 64, 8>(p, stream);
+        // C = 64 with the fragment-major weight: 4 x 16 output pixels (a 49 KB patch: three workgroups per CU hide each other's staging round trips) -- 35 -> 29 us at
+        // batch 16, 67 -> 51 at batch 32 (profiles/r06_run32_c64.txt); with the row-major weight the doubled weight stream costs what that wins
+        if (C == 64 && p.W_fm && Ho % 4 == 0 && Wo % 16 == 0) return launch_down_patch<T, 64, 4, 16, 128, 8>(p, stream);
         if (C == 64 && Ho % 8 == 0 && Wo % 16 == 0) return launch_down_patch<T, 64, 8, 16, 128, 8>(p, stream);
         // C >= 128 with ROW-MAJOR weights: one workgroup per CU (the patch is 90 KB) streaming 1-2 MB of weights -- a win while the launch is ONE round of workgroups, slower than the
         // first form beyond it (batch 32: 83 vs 71 us at C = 128, 132 vs 103 at C = 256; batch 16: 42 vs 53, 67 vs 76; profiles/r06_run28_down.txt)
