@@ -510,6 +510,40 @@ def test_fused_training_gemm_epilogues_equal_the_two_pass_forms(dtype, M, N, K):
     assert rel(ops.linear_mul_dgelu(a, w, zero, c), two_pass.float().cpu()) < pick(dtype, 1e-6, 8e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Cin,H,W,B,acc", [(32, 16, 32, 2, False), (32, 64, 64, 1, True), (64, 16, 32, 3, True), (128, 8, 32, 4, False), (128, 32, 64, 1, True), (256, 16, 32, 4, True), (256, 32, 32, 2, False)])
+def test_downsample_input_gradient_patch_form(dtype, Cin, H, W, B, acc, monkeypatch):
+    """uf_downsample_bwd's input gradient from an LDS patch of dy (down_dx_kernel: the four parity classes of ConvTranspose2d k4 s2 p1 as GEMMs over K = 4 taps x
+    Cout, every tap's product rounded to T and the taps added in ascending (ky, kx)) against the patch-matrix route (GEMM rounded to T + col2im;
+    UF_VARIANT="downdx=1"): BIT-IDENTICAL -- on maps that are one tile (every border inside it), several images, non-square maps, accumulation into an existing
+    gradient -- and both against the oracle (conv_transpose2d of the T-rounded operands in f64).  The weight / bias gradients do not depend on the form."""
+    from uformer_amd import ops, packing
+    Cout = 2 * Cin
+    x = torch.randn(B * H * W, Cin, generator=g(80 + Cin)).cuda()
+    dy = torch.randn(B * (H // 2) * (W // 2), Cout, generator=g(81)).cuda()
+    w4 = torch.randn(Cout, Cin, 4, 4, generator=g(82)) * (16 * Cin) ** -0.5
+    wpt = packing.pack_downsample(w4.cuda(), dtype).t().contiguous()
+    base = torch.randn(B * H * W, Cin, generator=g(83)).cuda()
+
+    def run():
+        add = base.clone() if acc else None
+        dx, dW, db = ops.downsample_bwd(x, dy, wpt, B, H, W, add_to=add)
+        return dx.clone(), dW.clone(), db.clone()
+
+    monkeypatch.setenv("UF_VARIANT", "downdx=1")
+    dx0, dW0, db0 = run()
+    monkeypatch.delenv("UF_VARIANT")
+    dx1, dW1, db1 = run()
+    torch.cuda.synchronize()
+    assert torch.equal(dW0, dW1) and torch.equal(db0, db1)
+    dyq, wq = dy.cpu().to(dtype).double(), w4.to(dtype).double()
+    ora = torch.nn.functional.conv_transpose2d(dyq.reshape(B, H // 2, W // 2, Cout).permute(0, 3, 1, 2), wq, stride=2, padding=1)
+    ora = ora.permute(0, 2, 3, 1).reshape(B * H * W, Cin).float() + (base.cpu() if acc else 0)
+    scale = ora.abs().max().item()
+    assert torch.equal(dx0, dx1), f"Cin={Cin} {H}x{W} B={B}: the two routes differ, max abs {(dx0 - dx1).abs().max().item():.3e}"
+    assert (dx1.cpu() - ora).abs().max().item() / scale < pick(dtype, 1e-6, 8e-3)
+
+
 @pytest.mark.parametrize("dtype", MODES)
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 64), (1, 8, 24, 128), (3, 32, 32, 32)])
 def test_fused_training_stencils_equal_the_two_pass_forms(dtype, B, H, W, C):

@@ -698,6 +698,165 @@ int try_down_patch(const GemmParams& p, hipStream_t stream, bool* done) {
     return UF_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Input gradient of Downsample on the recipe of down_patch_kernel (round 6; training, 2-byte operand types, Cin = 32 ... 256).
+// dx = ConvTranspose2d(dy; k4 s2 p1): input pixel (2a + r, 2b + s) collects FOUR taps -- ky in {3, 1} (r = 0) or {2, 0} (r = 1) from output rows a - 1 + r, a + r,
+// likewise kx -- so each of the four parity classes (r, s) is a GEMM over the (a, b) grid with K = 4 taps x Cout and N = Cin.  The first form is
+// uf_linear_fwd (dy W -> the 16 Cin-wide patch matrix, rounded to T) + uf_col2im: the patch matrix goes through HBM twice (1 GB per step at batch 32).
+// Here a workgroup owns TOY x TOX positions (a, b), stages the (TOY + 2) x (TOX + 2) pixels of dy around them in LDS once (zero outside the map), and
+// computes the four classes from it: operand fragments are 16-byte LDS reads (pixel pitch 2 Cout + 32 bytes: neighbouring pixels hit different bank
+// groups), the class's weight [Cin][4 Cout] streams fragment-major L2 -> registers (down_dx_pack_kernel builds the four class weights from the transposed
+// packed weight).  Every tap's product is rounded to T and the taps are added in ascending (ky, kx), as the first form does: bit-identical to it.
+// ------------------------------------------------------------------------------------------------------------------
+struct DownDxParams {
+    const void* dyT; int ld_dy;      // T[B * Ho * Wo][ld_dy]: the output gradient in the operand type
+    const void* Wc;                  // fragment-major T[4][Cin][4 Cout]
+    float* dx; int ld_dx;            // f32[B * H * W][ld_dx]
+    int B, H, W, accumulate;         // H, W: the INPUT map
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void down_dx_pack_kernel(const T* __restrict__ w_pk_t, T* __restrict__ out, int Ci, int Co) {
+    // out[cls][n-tile][k-step][lane = fg * 16 + fr][8] = W_cls[n = 16 tile + fr][k = 32 ks + 8 fg ..], W_cls[ci][t Co + co] = w_pk_t[(ky(r, ty) 4 + kx(s, tx)) Ci + ci][co]
+    const int KSN = (4 * Co) / 32, NT = Ci / 16;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)4 * NT * KSN * 64) return;
+    const int lane = (int)(idx & 63), fr = lane & 15, fg = lane >> 4;
+    long long rest = idx >> 6;
+    const int ks = (int)(rest % KSN); rest /= KSN;
+    const int nt = (int)(rest % NT), cls = (int)(rest / NT);
+    const int r = cls >> 1, sx = cls & 1;
+    const int k0 = ks * 32 + fg * 8, t = k0 / Co, co = k0 - t * Co, ty = 1 - (t >> 1), tx = 1 - (t & 1);       // taps in ascending (ky, kx): the order uf_col2im adds them in
+    const int ky = r == 0 ? (ty == 0 ? 3 : 1) : (ty == 0 ? 2 : 0), kx = sx == 0 ? (tx == 0 ? 3 : 1) : (tx == 0 ? 2 : 0);
+    const int n = nt * 16 + fr;
+    *reinterpret_cast<u32x4*>(out + idx * 8) = *reinterpret_cast<const u32x4*>(w_pk_t + ((size_t)((ky * 4 + kx) * Ci + n)) * Co + co);
+}
+
+template <typename T, int CI, int TOY, int TOX, int RING>
+__global__ __launch_bounds__(256, CI <= 64 ? 2 : 1) void down_dx_kernel(const DownDxParams p, int tiles_x, int tiles_y) {
+    static_assert(sizeof(T) == 2 && TOX == 16, "2-byte operand types; 16-position tile rows");
+    constexpr int CO = 2 * CI, PH = TOY + 2, PW = TOX + 2, PP = CO * 2 + 32, TOK = TOY * TOX;
+    constexpr int WN = CI / 16 >= 4 ? 4 : CI / 16, WM = 4 / WN;             // waves along the input channels / along the positions
+    constexpr int TN = CI / 16 / WN, TM = TOK / 16 / WM;
+    constexpr int KST = CO / 32, KSN = 4 * KST;                             // k-steps per tap, per class
+    static_assert(KSN % RING == 0 && TOK % (16 * WM) == 0, "ring / tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wn = wave % WN, wm = wave / WN;
+    const int tile = xcd_tile((int)blockIdx.x, (int)gridDim.x);
+    const int b = tile / (tiles_x * tiles_y), tr = tile - b * (tiles_x * tiles_y);
+    const int a0 = (tr / tiles_x) * TOY, b0 = (tr % tiles_x) * TOX;
+    const int Ho = p.H >> 1, Wo = p.W >> 1;
+    const T* dy = reinterpret_cast<const T*>(p.dyT);
+    const T* Wc = reinterpret_cast<const T*>(p.Wc);
+    // ---- the dy pixels around the tile: 16-byte chunks (8 channels), all of a thread's loads in flight before its stores; zero outside the map
+    {
+        constexpr int CPP = CO / 8, NCH = PH * PW * CPP, PER = (NCH + 255) / 256;
+        u32x4 v[PER];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = q * 256 + tid, ic = idx < NCH ? idx : NCH - 1;
+            const int pix = ic / CPP, cc = ic - pix * CPP, pr = pix / PW, pc = pix - pr * PW;
+            const int oy = a0 - 1 + pr, ox = b0 - 1 + pc;
+            const bool ok = oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+            const int oyc = oy < 0 ? 0 : (oy >= Ho ? Ho - 1 : oy), oxc = ox < 0 ? 0 : (ox >= Wo ? Wo - 1 : ox);
+            v[q] = *reinterpret_cast<const u32x4*>(dy + ((size_t)(b * Ho + oyc) * Wo + oxc) * p.ld_dy + cc * 8);
+            if (!ok) v[q] = u32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+            const int idx = q * 256 + tid;
+            if (idx < NCH) {
+                const int pix = idx / CPP, cc = idx - pix * CPP;
+                *reinterpret_cast<u32x4*>(smem + pix * PP + cc * 16) = v[q];
+            }
+        }
+    }
+    __syncthreads();
+    int abase[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) abase[j] = ((wm * TM + j) * PW + fr) * PP + fg * 16;      // TOX = 16: position tile j = tile row, lane fr = column
+#pragma unroll 1
+    for (int cls = 0; cls < 4; ++cls) {
+        const int r = cls >> 1, sx = cls & 1;
+        const T* wrow[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wrow[i] = Wc + (((size_t)cls * (CI / 16) + wn * TN + i) * KSN * 64 + lane) * 8;
+        Frag<T> wf[RING][TN];
+#pragma unroll
+        for (int q = 0; q < RING - 1; ++q)
+#pragma unroll
+            for (int i = 0; i < TN; ++i) load_frag(wf[q][i], wrow[i] + q * 512);
+        // one accumulator per tap, folded into the f32 sum ROUNDED TO T, taps in ascending (ky, kx): exactly what the patch-matrix route computes (its GEMM
+        // stores every tap's product as T, uf_col2im adds them in that order) -- the two routes are bit-identical
+        f32x4 acc[TN][TM], sum[TN][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j) { acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; sum[i][j] = acc[i][j]; }
+        const int cbase = (r * PW + sx) * PP;
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            if (ks + RING - 1 < KSN) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) load_frag(wf[(ks + RING - 1) % RING][i], wrow[i] + (ks + RING - 1) * 512);
+            }
+            const int t = ks / KST, koff = cbase + ((1 - (t >> 1)) * PW + (1 - (t & 1))) * PP + (ks - t * KST) * 64;
+            Frag<T> af[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) load_frag(af[j], reinterpret_cast<const T*>(smem + abase[j] + koff));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[ks % RING][i], af[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((ks + 1) % KST == 0) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j) {
+                        float lo0, lo1, hi0, hi1;
+                        unpack2<T>(pack2<T>(acc[i][j][0], acc[i][j][1]), lo0, lo1);
+                        unpack2<T>(pack2<T>(acc[i][j][2], acc[i][j][3]), hi0, hi1);
+                        sum[i][j] += f32x4{lo0, lo1, hi0, hi1};
+                        acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int ci = (wn * TN + i) * 16 + 4 * fg;
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int a = a0 + wm * TM + j, bb = b0 + fr;
+                float* o = p.dx + ((size_t)(b * p.H + 2 * a + r) * p.W + 2 * bb + sx) * p.ld_dx + ci;
+                f32x4 v = sum[i][j];
+                if (p.accumulate) v += *reinterpret_cast<const f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = v;
+            }
+        }
+    }
+}
+
+template <typename T, int CI, int TOY, int RING>
+int launch_down_dx_t(const DownDxParams& p, hipStream_t st) {
+    constexpr int CO = 2 * CI, smem = (TOY + 2) * 18 * (CO * 2 + 32);
+    auto kern = down_dx_kernel<T, CI, TOY, 16, RING>;
+    static bool lds_done[64] = {};
+    if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(kern), smem, lds_done, "downsample dx")) return rc;
+    const int Ho = p.H / 2, Wo = p.W / 2, tiles_x = Wo / 16, tiles_y = Ho / TOY;
+    char name[96] = "";
+    if (timing_enabled()) snprintf(name, sizeof(name), "down_dx_%s_c%d %dx%dx%d", TypeName<T>::s, CI, p.B * p.H * p.W, CI, 4 * CO);
+    {
+        ScopedTimer tm(name, 2.0 * p.B * p.H * p.W * CI * 4.0 * CO, (double)p.B * Ho * Wo * CO * sizeof(T) + (double)p.B * p.H * p.W * CI * 4 * (p.accumulate ? 2 : 1), st);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * tiles_x * tiles_y)), dim3(256), smem, st, p, tiles_x, tiles_y);
+    }
+    return check_launch("downsample dx");
+}
+
 template <typename T>
 int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
     if (aload == A_PLAIN) {
@@ -724,6 +883,33 @@ int launch_t(const GemmParams& p, int aload, int epi, hipStream_t stream) {
 }
 
 }  // namespace
+
+// Input gradient of Downsample from an LDS patch of dy (see down_dx_kernel).  Returns UF_OK with *done = false where the form is not built (the caller runs
+// uf_linear_fwd + uf_col2im).  wc: scratch for the four class weights, 16 Cin Cout elements of T.
+int launch_down_dx(const void* dyT, int ld_dy, const void* w_pk_t, void* wc, float* dx, int ld_dx, int B, int H, int W, int Cin, int Cout, int accumulate, uf_dtype dtype,
+                   hipStream_t st, bool* done) {
+    *done = false;
+    const int Ho = H / 2, Wo = W / 2;
+    if (!dtype_half(dtype) || Cout != 2 * Cin || (Cin != 32 && Cin != 64 && Cin != 128 && Cin != 256) || (H & 1) || (W & 1) || Wo % 16 || ld_dy % 8 || ld_dx % 4 ||
+        variant("downdx", 2) == 1) return UF_OK;
+    const int toy = Cin <= 64 ? 8 : 4;
+    if (Ho % toy || ((uintptr_t)dyT % 16) || ((uintptr_t)dx % 16) || ((uintptr_t)wc % 16) || ((uintptr_t)w_pk_t % 16)) return UF_OK;
+    *done = true;
+    const long long groups = (long long)4 * (Cin / 16) * ((4 * Cout) / 32) * 64;
+    DownDxParams p{dyT, ld_dy, wc, dx, ld_dx, B, H, W, accumulate};
+#define UF_DDX(TT)                                                                                                                                        \
+    hipLaunchKernelGGL(down_dx_pack_kernel<TT>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, (const TT*)w_pk_t, (TT*)wc, Cin, Cout);         \
+    if (int rc = check_launch("downsample dx pack")) return rc;                                                                                           \
+    switch (Cin) {                                                                                                                                        \
+        case 32: return launch_down_dx_t<TT, 32, 8, 8>(p, st);                                                                                            \
+        case 64: return launch_down_dx_t<TT, 64, 8, 8>(p, st);                                                                                            \
+        case 128: return launch_down_dx_t<TT, 128, 4, 8>(p, st);                                                                                          \
+        default: return launch_down_dx_t<TT, 256, 4, 4>(p, st);                                                                                           \
+    }
+    if (dtype == UF_BF16) { UF_DDX(bf16) }
+    UF_DDX(f16)
+#undef UF_DDX
+}
 
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream) {
     const int epc = dtype_half(dtype) ? 8 : 4;

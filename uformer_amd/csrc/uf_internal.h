@@ -35,6 +35,9 @@ struct GemmParams {
 
 // dtype-dispatching launcher; AL/EP are the enums above.  Returns UF_* status.
 int launch_gemm(const GemmParams& p, int aload, int epi, uf_dtype dtype, hipStream_t stream);
+// input gradient of Downsample from an LDS patch of dy (uf_gemm.hip, round 6); *done = false where the form is not built
+int launch_down_dx(const void* dyT, int ld_dy, const void* w_pk_t, void* wc, float* dx, int ld_dx, int B, int H, int W, int Cin, int Cout, int accumulate, uf_dtype dtype,
+                   hipStream_t st, bool* done);
 
 // Side streams.  A LANE = {side streams, fork / join events, general-purpose events}; a call owns one lane exclusively between
 // acquire_lane and release_lane, so concurrent callers on one device never record or wait on each other's events (uf_core.hip).

@@ -319,6 +319,13 @@ extern "C" int uf_downsample_bwd(const float* x, int ld_x, const float* dy, cons
     UF_TRY(uf_im2col(x, ld_x, cols, K, B, H, W, Cin, 4, 2, 1, 0, dtype, stream));
     UF_TRY(uf_grad_fork(dy, nullptr, nullptr, dyT, nullptr, 1, 1, Mo, Cout, 0, 0, dtype, stream));                          // cast to the operand type
     UF_TRY(uf_linear_wgrad(dyT, Cout, cols, K, dW_pk, db, Mo, Cout, K, dtype, wg, wg_bytes, stream));
+    // input gradient: from an LDS patch of dy where that form is built (round 6: the 16 Cin-wide patch matrix never exists; the four class weights are packed into the
+    // space it would take), else the patch-matrix route
+    if ((size_t)Mo * K >= (size_t)16 * Cin * Cout) {
+        bool done = false;
+        UF_TRY(launch_down_dx(dyT, Cout, w_pk_t, dcols, dx, ld_dx, B, H, W, Cin, Cout, accumulate, dtype, (hipStream_t)stream, &done));
+        if (done) return UF_OK;
+    }
     UF_TRY(uf_linear_fwd(dyT, w_pk_t, zero, dcols, Mo, K, Cout, 0, dtype, stream));
     return uf_col2im(dcols, K, dx, ld_dx, B, H, W, Cin, 4, 2, 1, 0, accumulate, dtype, stream);
 }
