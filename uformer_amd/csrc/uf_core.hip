@@ -24,6 +24,7 @@ static thread_local char g_err[512] = "";
 //   stem=1, head=1  the first (global-load) forms of input_proj / output_proj instead of the LDS-staged ones
 //   down=1|2        Downsample: the im2col-loader GEMM everywhere / the LDS-patch form wherever it is built (round 6)
 //   attpair=0       window_attn_bwd2: (head, chunk) in launch order instead of head pairs per XCD (round 6)
+//   downdx=1        uf_downsample_bwd: the input gradient through the patch matrix (GEMM + col2im) instead of the LDS-patch kernel (round 6)
 // Read per call (a getenv and a scan of a short string beside a kernel launch): the tests flip keys inside one process.  Returns `dflt` without the key.
 int variant(const char* key, int dflt) {
     const char* e = getenv("UF_VARIANT");
